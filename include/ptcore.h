@@ -1,0 +1,294 @@
+/*
+ * ptcore.h — C ABI of the MI355X (gfx950) ray-tracing core.
+ *
+ * The library stands in for the Vulkan compute dispatch of JovianGraphics/PathTracer:
+ * it keeps that renderer's buffer layouts (ShaderData.h / structures.glsl) and mirrors
+ * its dispatch sites (PathTracer.cpp:776-838) one entry point each.  All signatures are
+ * plain C: pointers, sizes and integer status codes; no exceptions cross this boundary.
+ *
+ * Every entry point cites the reference interface it replaces as file:line relative to
+ * the reference checkout.
+ *
+ * Status codes: 0 = success, negative = failure; pt_last_error() gives the text.
+ */
+#ifndef PTCORE_H
+#define PTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * Data contract.  Sizes and offsets are checked by static asserts at the end of this file.
+ * ---------------------------------------------------------------------------------------- */
+
+/* ShaderData.h:9-13, structures.glsl:7-11 — per-vertex shading attributes, 16 B. */
+typedef struct PtVertexAux {
+    float   normal[3];
+    uint8_t color[4];            /* RGBA8; alpha < 128 marks the refractive ("delta") material */
+} PtVertexAux;
+
+/* ShaderData.h:15-28, structures.glsl:59-72 — the uniform block, 320 B, column-major mat4. */
+typedef struct PtShaderConstants {
+    float    viewMtx[16];
+    float    projMtx[16];
+    float    viewInvMtx[16];
+    float    projInvMtx[16];
+    float    viewportSize[2];
+    float    viewportBase[2];    /* never written by the reference host (PathTracer.cpp:742-750): keep 0 */
+    uint32_t numLights;
+    uint32_t numTriangles;
+    uint32_t frameIndex;
+    uint32_t numRays;            /* ray-stack slots per pixel = maximum path depth */
+    uint32_t numBVHNodes;
+    uint32_t _pad0[3];
+    float    ambientRadiance[3];
+    uint32_t _pad1;
+} PtShaderConstants;
+
+/* ShaderData.h:30-34, structures.glsl:1-5 — point light, 32 B. */
+typedef struct PtLight {
+    float pos[3];      float _pad0;
+    float radiance[3]; float _pad1;
+} PtLight;
+
+/* structures.glsl:43-52 — one ray-stack slot, 48 B.  (The host twin ShaderData.h:36-42 has a
+ * different field order; only its sizeof is used, PathTracer.cpp:448.)  Half fields are raw
+ * IEEE binary16 bit patterns. */
+typedef struct PtRayStackSlot {
+    float    rayDirection[3];
+    uint32_t randState;
+    float    rayOrigin[3];
+    uint32_t currentDepth;
+    uint16_t hitAlbedo[4];
+    uint16_t wIn[3];
+    uint16_t prob;
+} PtRayStackSlot;
+
+/* ShaderData.h:44-47, structures.glsl:54-57 — a job is the index of a live slot or PT_JOB_DEAD. */
+typedef struct PtRayJob { uint32_t index; } PtRayJob;
+#define PT_JOB_DEAD 0xFFFFFFFFu
+
+/* BVH.h:27-33, structures.glsl:35-41 — threaded binary BVH node, 32 B.
+ * right > 0: interior, index of right child (left child is own index + 1).
+ * right <= 0: leaf, -right is the offset of its triangle in the (reordered) index array.
+ * next: node to continue with when this node's box is missed; 0 ends the walk. */
+typedef struct PtBVHNode {
+    float   a[3]; int32_t next;
+    float   b[3]; int32_t right;
+} PtBVHNode;
+
+/* structures.glsl:13-18 (the o/min_t/d/max_t prefix of Ray) — 32 B ray of the traversal microbench. */
+typedef struct PtRay {
+    float o[3]; float min_t;
+    float d[3]; float max_t;
+} PtRay;
+
+/* Result of one traversal: t and the vertex-index triple of the hit triangle
+ * (intersections.glsl:47-52); a miss has i1 = i2 = i3 = -1 and t = the ray's max_t. */
+typedef struct PtHit {
+    float   t;
+    int32_t i1, i2, i3;
+} PtHit;
+
+/* Flattened two-wide node, 64 B: the boxes of both children of one interior node of the
+ * reference tree, pre-digested exactly as intersections.glsl:3-5 does per visit
+ * (c = (a+b)*0.5f in fp32, hA = f16(a-c), hB = f16(b-c)); nothing is re-quantised.
+ * Child reference: bit 31 set = leaf, low 31 bits = index into the triangle records;
+ * clear = index into the PtNode2 array. */
+typedef struct PtNode2 {
+    float    cL[3];
+    uint16_t hL[6];              /* f16(aL-cL) xyz, f16(bL-cL) xyz */
+    float    cR[3];
+    uint16_t hR[6];
+    uint32_t left, right;
+    uint32_t refIndex;           /* index of this interior node in the reference array */
+    uint32_t _pad;
+} PtNode2;
+
+/* Flattened leaf, 64 B: the triangle the reference reaches through two dependent texel
+ * fetches (intersections.glsl:86-94), stored inline.  e1 = p2-p1 and e2 = p3-p1 are the
+ * fp32 differences intersections.glsl:34-35 computes per test. */
+typedef struct PtTri {
+    float    p1[3];  int32_t i1;
+    float    e1[3];  int32_t i2;
+    float    e2[3];  int32_t i3;
+    uint32_t refLeaf;            /* index of the leaf node in the reference array */
+    uint32_t flags;              /* bit 0: last node of the reference array */
+    uint32_t _pad[2];
+} PtTri;
+#define PT_LEAF_BIT 0x80000000u
+
+/* ------------------------------------------------------------------------------------------
+ * Host-side scene preparation (no GPU needed).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Replaces HimaliaPlyModel::LoadFile + BuildVertices + BuildIndices (PathTracer.cpp:246-262).
+ * Reads ASCII and binary_little_endian PLY with x,y,z[,nx,ny,nz][,red,green,blue[,alpha]]
+ * vertices and `list uchar uint|int vertex_indices` faces; polygons are fan-triangulated.
+ * Call once with all output pointers NULL to get the counts, then again with buffers:
+ * positions = 4 floats per vertex (w = 1), aux = PtVertexAux per vertex, indices = 3 per triangle. */
+PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint32_t* num_triangles,
+                       float* positions, PtVertexAux* aux, uint32_t* indices,
+                       char* err, size_t err_len);
+
+/* Replaces BuildBVH (BVH.cpp:83-309).  positions: vec4 per vertex; indices: 3 per triangle,
+ * reordered in place exactly as the reference does; nodes: room for 2*T-1 entries.
+ * The node array is bit-identical to the reference's single-threaded build for any
+ * num_threads (0 = all hardware threads).  max_depth may be NULL. */
+PT_API int pt_build_bvh(const float* positions, uint32_t num_vertices,
+                        uint32_t* indices, uint32_t num_triangles,
+                        PtBVHNode* nodes, uint32_t* max_depth, int num_threads,
+                        char* err, size_t err_len);
+
+/* The flattening pass added to BVH.cpp: turns the threaded 32 B node array into PtNode2
+ * (T-1 entries) and PtTri (T entries) records.  root_box receives the root's a,b (6 floats). */
+PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
+                          const float* positions, const uint32_t* indices, uint32_t num_triangles,
+                          PtNode2* nodes2, PtTri* tris, float* root_box, uint32_t* max_stack,
+                          char* err, size_t err_len);
+
+/* Replaces the constants block filled at PathTracer.cpp:731-750 (glm::lookAt, glm::perspective
+ * with the y flip, glm::inverse) for the orbit camera of PathTracer.cpp:109-112. */
+PT_API void pt_fill_constants(PtShaderConstants* c, uint32_t width, uint32_t height,
+                              const float focus_center[3], float orbit_height, float orbit_radius,
+                              float orbit_angle, uint32_t num_lights, uint32_t num_triangles,
+                              uint32_t frame_index, uint32_t num_rays, uint32_t num_bvh_nodes,
+                              const float ambient[3]);
+
+/* ------------------------------------------------------------------------------------------
+ * Device context.  One context per GPU per process; all work of a context runs in order on
+ * one HIP stream, which replaces the Vulkan barriers of PathTracer.cpp:782-818.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct PtContext PtContext;
+
+PT_API int         pt_ctx_create(int device_id, PtContext** out);
+PT_API void        pt_ctx_destroy(PtContext* ctx);
+PT_API const char* pt_last_error(PtContext* ctx);      /* ctx may be NULL: last create error */
+PT_API int         pt_synchronize(PtContext* ctx);
+PT_API void*       pt_stream(PtContext* ctx);          /* the context's hipStream_t */
+
+/* Options (no reference counterpart; they select among documented behaviours). */
+enum {
+    PT_OPT_TRAVERSAL      = 1,   /* 0 = reference 32 B nodes, stackless walk; 1 = PtNode2, reference visit
+                                    order (default, results identical to 0); 2 = PtNode2, near child first */
+    PT_OPT_STALE_SLOTS    = 2,   /* 0 = zero prob of the next slot when a path ends (default); 1 = leave
+                                    deeper slots as they are, as composite.frag:35-49 finds them */
+    PT_OPT_RESEED         = 3,   /* 0 = seed the LCG only after a clear (launch.comp:49-50, default);
+                                    1 = reseed every frame (needed when frames are split over GPUs) */
+    PT_OPT_PERSIST_BLOCKS = 4,   /* workgroups (256 lanes) per CU of the persistent traversal kernels */
+    PT_OPT_REFILL_MIN     = 5    /* a wavefront refills its idle lanes once this many of its 64 are idle */
+};
+PT_API int pt_set_option(PtContext* ctx, int option, int value);
+PT_API int pt_get_option(PtContext* ctx, int option, int* value);
+
+/* Replaces the six CreateBuffer + UploadToBufferEx calls of PathTracer.cpp:272-321 (bindings
+ * 1,2,3,4,7,8 of PathTracer.cpp:490-502).  Host pointers are borrowed for the call only.
+ * `nodes` is the reference-layout array; the flattening pass runs inside. */
+PT_API int pt_scene_upload(PtContext* ctx,
+                           const float* positions, uint32_t num_vertices,
+                           const PtVertexAux* aux,
+                           const uint32_t* indices, uint32_t num_triangles,
+                           const PtBVHNode* nodes, uint32_t num_nodes,
+                           const PtLight* lights, uint32_t num_lights,
+                           const uint16_t* blue_noise /* 65536 entries */);
+
+/* Replaces the per-resolution resources of PathTracer.cpp:378-459 (bindings 5,6,9,10):
+ * current image RGBA16F, accumulation RGBA32F, ray stack 48 B x W x H x max_slots, jobs. */
+PT_API int pt_resize(PtContext* ctx, uint32_t width, uint32_t height, uint32_t max_slots);
+
+/* Replaces the transient uniform slice written at PathTracer.cpp:731-752 (binding 0). */
+PT_API int pt_set_constants(PtContext* ctx, const PtShaderConstants* constants);
+
+/* Replaces ClearImage(accumulation) at PathTracer.cpp:947-950. */
+PT_API int pt_clear_accumulation(PtContext* ctx);
+
+/* Dispatch sites, in the order PathTracer.cpp records them. */
+PT_API int pt_launch(PtContext* ctx);                               /* PathTracer.cpp:776-778, launch.comp */
+PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative);/* PathTracer.cpp:788-793, trace.comp */
+PT_API int pt_compact(PtContext* ctx);                              /* PathTracer.cpp:795-811, raysort.comp */
+PT_API int pt_resolve_accumulate(PtContext* ctx);                   /* PathTracer.cpp:835-836, composite.frag:30-55 */
+
+/* One whole frame = one sample per pixel: set frameIndex, launch, numRays x {trace, compact},
+ * resolve + accumulate (PathTracer.cpp:729-838).  ray_counts, if not NULL, receives 2*numRays
+ * uint64: closest-hit rays and shadow rays traced at each depth. */
+PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculative_depth0,
+                            uint64_t* ray_counts);
+
+/* Replaces the dump read-back of PathTracer.cpp:848-854 (RGBA16F current image) and adds the
+ * linear accumulation (RGBA32F, .w = sample count).  Host destination buffers. */
+PT_API int pt_readback_current(PtContext* ctx, uint16_t* rgba16f);
+PT_API int pt_readback_accumulation(PtContext* ctx, float* rgba32f);
+PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob* jobs);
+PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const PtRayJob* jobs);
+PT_API void* pt_accumulation_device_ptr(PtContext* ctx);           /* 4 floats x W x H, for the all-reduce */
+
+/* Traversal microbench (no reference dispatch site; it calls traceRay, intersections.glsl:57-115,
+ * on caller-supplied rays).  d_rays / d_hits are DEVICE pointers; stats, if not NULL, is a host
+ * array of 4 uint64 that receives {box tests, triangle tests, node records fetched, rays} (a
+ * counting build of the same kernel runs instead of the plain one). */
+PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit,
+                         PtHit* d_hits, uint64_t* stats);
+/* Same with HOST pointers: copies in, traces, copies out. */
+PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t num_rays, int any_hit,
+                              PtHit* hits, uint64_t* stats);
+/* Fills d_rays[0..n) with the synthetic incoherent ray set: ray i takes five 24-bit uniforms from
+ * successive splitmix64 outputs of state seed + (first+i)*0x9E3779B97F4A7C15; origin uniform in the
+ * scene's root box, direction uniform on the sphere, min_t = 0.001, max_t = 1e5. */
+PT_API int pt_generate_rays(PtContext* ctx, uint64_t seed, uint64_t first, uint64_t n, PtRay* d_rays);
+
+PT_API void* pt_device_alloc(PtContext* ctx, size_t bytes);
+PT_API int   pt_device_free(PtContext* ctx, void* p);
+PT_API int   pt_copy_to_host(PtContext* ctx, void* dst, const void* d_src, size_t bytes);
+PT_API int   pt_copy_to_device(PtContext* ctx, void* d_dst, const void* src, size_t bytes);
+
+/* Time of the last traversal launch in milliseconds, measured with HIP events on the
+ * context's stream (closest-hit launch of pt_trace_rays, or the sum over a pt_render_sample). */
+PT_API float pt_last_kernel_ms(PtContext* ctx);
+
+/* Multi-GPU (no reference counterpart): sums the accumulation buffers of all ranks in place.
+ * unique_id is the 128-byte ncclUniqueId made by pt_comm_unique_id on rank 0 and handed to
+ * every rank by the caller. */
+PT_API int pt_comm_unique_id(uint8_t unique_id[128]);
+PT_API int pt_comm_init(PtContext* ctx, int rank, int num_ranks, const uint8_t unique_id[128]);
+PT_API int pt_allreduce_accumulation(PtContext* ctx);
+
+PT_API const char* pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+/* Layout checks (C11 / C++11). */
+#ifdef __cplusplus
+#define PT_SA(c, m) static_assert(c, m)
+#else
+#define PT_SA(c, m) _Static_assert(c, m)
+#endif
+PT_SA(sizeof(PtVertexAux) == 16, "VertexAux is 16 B");
+PT_SA(offsetof(PtVertexAux, color) == 12, "VertexAux.color at 12");
+PT_SA(sizeof(PtShaderConstants) == 320, "ShaderConstants is 320 B");
+PT_SA(offsetof(PtShaderConstants, viewportSize) == 256, "viewportSize at 256");
+PT_SA(offsetof(PtShaderConstants, viewportBase) == 264, "viewportBase at 264");
+PT_SA(offsetof(PtShaderConstants, numLights) == 272, "numLights at 272");
+PT_SA(offsetof(PtShaderConstants, frameIndex) == 280, "frameIndex at 280");
+PT_SA(offsetof(PtShaderConstants, numRays) == 284, "numRays at 284");
+PT_SA(offsetof(PtShaderConstants, numBVHNodes) == 288, "numBVHNodes at 288");
+PT_SA(offsetof(PtShaderConstants, ambientRadiance) == 304, "ambientRadiance at 304");
+PT_SA(sizeof(PtLight) == 32 && offsetof(PtLight, radiance) == 16, "Light is 32 B");
+PT_SA(sizeof(PtRayStackSlot) == 48, "ray-stack slot is 48 B");
+PT_SA(offsetof(PtRayStackSlot, randState) == 12 && offsetof(PtRayStackSlot, rayOrigin) == 16 &&
+      offsetof(PtRayStackSlot, currentDepth) == 28 && offsetof(PtRayStackSlot, hitAlbedo) == 32 &&
+      offsetof(PtRayStackSlot, wIn) == 40 && offsetof(PtRayStackSlot, prob) == 46, "slot field offsets");
+PT_SA(sizeof(PtRayJob) == 4, "job is 4 B");
+PT_SA(sizeof(PtBVHNode) == 32 && offsetof(PtBVHNode, next) == 12 && offsetof(PtBVHNode, b) == 16 &&
+      offsetof(PtBVHNode, right) == 28, "BVHNode is 32 B");
+PT_SA(sizeof(PtRay) == 32 && sizeof(PtHit) == 16, "microbench ray 32 B, hit 16 B");
+PT_SA(sizeof(PtNode2) == 64 && sizeof(PtTri) == 64, "flattened records are 64 B");
+
+#endif /* PTCORE_H */

@@ -1,0 +1,47 @@
+"""Builds pathtracer_amd/libptcore.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libptcore.so")
+SOURCES = ["ptcore.hip", "bvh_build.cpp", "ply.cpp", "scene_prep.cpp"]
+HEADERS = ["device_math.h", "trace_kernels.h", "frame_kernels.h", "../../include/ptcore.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the reference's arithmetic is restated operation by operation; a fused
+# multiply-add would change results.  Division and sqrt stay correctly rounded (hipcc default).
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fvisibility=hidden",
+         "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    for src in SOURCES:
+        path = os.path.join(CSRC, src)
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", path, "-o", path + ".o"]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "c++")
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(path + ".o")
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-pthread"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

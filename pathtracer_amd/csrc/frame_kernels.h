@@ -1,0 +1,312 @@
+/*
+ * frame_kernels.h — the wavefront stages around traversal: ray generation, shading with
+ * next-event estimation, job compaction, path resolve + accumulate.
+ *
+ * The reference fuses closest-hit, shading, the shadow-ray walk and the spawn of the next ray in
+ * one kernel (reference trace.comp:165-233).  Here they are separate passes over dense queues:
+ *   k_launch            -> slot 0 of every pixel + one job per pixel          (launch.comp:28-51)
+ *   k_trace_*<JOBS>     -> one PtHitRec per job                               (trace_kernels.h)
+ *   k_shade             -> slot fields, the next slot, one PtShadowRay per hit (trace.comp:58-233)
+ *   k_trace_*<SHADOW>   -> clears wIn of slots whose light sample is occluded (trace.comp:123)
+ *   k_compact           -> dense list of the jobs still alive                 (raysort.comp:23-55)
+ *   k_resolve           -> radiance per pixel, += accumulation                (composite.frag:30-55)
+ * All shading arithmetic is fp16 as in the reference, one rounding per operation.
+ */
+#pragma once
+#include "../../include/ptcore.h"
+#include "device_math.h"
+#include "trace_kernels.h"
+
+#pragma clang fp contract(off)
+
+enum {
+    CTR_NJOBS = 0,        /* entries of the current job list */
+    CTR_NSHADOW = 1,      /* shadow rays queued by the shade pass */
+    CTR_FETCH_CLOSEST = 2,
+    CTR_FETCH_SHADOW = 3,
+    CTR_COMPACT_OUT = 4,
+    CTR_LIVE = 5,         /* live jobs seen by the shade pass = closest-hit rays traced */
+    CTR_WORDS = 8
+};
+
+struct FrameArgs {
+    PtShaderConstants c;
+    uint32_t W, H, slots;
+    uint32_t zeroNextSlot, reseed;
+    PtRayStackSlot* stack;
+    uint32_t* jobs;
+    uint32_t* jobsOut;
+    uint32_t* ctr;
+    const PtHitRec* hitRecs;
+    PtShadowRay* shadowRays;
+    const PtVertexAux* aux;
+    const PtLight* lights;
+    const uint16_t* blueNoise;
+    float4* accumulation;
+    uint2* current;                  /* RGBA16F */
+    unsigned long long* rayCounts;   /* [2*depth] closest rays, [2*depth+1] shadow rays */
+};
+
+__device__ __forceinline__ void mat_mul_vec(const float* m, const float v[4], float out[4])
+{
+    for (int i = 0; i < 4; i++) out[i] = ((m[0 + i] * v[0] + m[4 + i] * v[1]) + m[8 + i] * v[2]) + m[12 + i] * v[3];
+}
+
+/* launch.comp:28-51 */
+__global__ __launch_bounds__(256) void k_launch(FrameArgs f)
+{
+    const uint32_t gx = blockIdx.x * 32 + (threadIdx.x & 31), gy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const uint32_t lx = gx + (uint32_t)f.c.viewportBase[0], ly = gy + (uint32_t)f.c.viewportBase[1];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) f.ctr[CTR_NJOBS] = f.W * f.H;
+    if ((float)lx >= f.c.viewportSize[0] || (float)ly >= f.c.viewportSize[1]) return;
+    uint32_t jitter = (uint32_t)f.blueNoise[(lx & 0xFF) + ((ly & 0xFF) << 8)] * 256u + (uint32_t)f.blueNoise[f.c.frameIndex & 0xFFFF];
+    h16 wx, wy; WeylNth(jitter, wx, wy);
+    float px = (((float)lx + (float)wx) / f.c.viewportSize[0]) * 2.0f - 1.0f;
+    float py = (((float)ly + (float)wy) / f.c.viewportSize[1]) * 2.0f - 1.0f;
+    float projPos[4] = { px, py, 1.0f, 1.0f }, viewPos[4], world[4], cam[4];
+    mat_mul_vec(f.c.projInvMtx, projPos, viewPos);
+    float vw = viewPos[3];
+    for (int k = 0; k < 4; k++) viewPos[k] /= vw;
+    mat_mul_vec(f.c.viewInvMtx, viewPos, world);
+    const float origin[4] = { 0, 0, 0, 1 };
+    mat_mul_vec(f.c.viewInvMtx, origin, cam);
+    float cw = cam[3];
+    for (int k = 0; k < 4; k++) cam[k] /= cw;
+
+    const uint32_t jobIndex = ly * (uint32_t)f.c.viewportSize[0] + lx, stackIndex = jobIndex * f.c.numRays;
+    PtRayStackSlot* s = f.stack + stackIndex;
+    F3 d = { world[0] - cam[0], world[1] - cam[1], world[2] - cam[2] };
+    float inv = 1.0f / __builtin_sqrtf(fdot(d, d));
+    uint32_t rs = s->randState;
+    if (f.reseed || f.accumulation[jobIndex].w < 0.5f) rs = jitter;
+    float4* sp = (float4*)s;
+    sp[0] = make_float4(d.x * inv, d.y * inv, d.z * inv, __uint_as_float(rs));
+    sp[1] = make_float4(cam[0], cam[1], cam[2], __uint_as_float(0u));
+    s->prob = 0;
+    f.jobs[jobIndex] = stackIndex;
+}
+
+/* trace.comp:58-233 minus the two walks */
+__global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t njobs = f.ctr[CTR_NJOBS];
+    uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
+    const bool live = slot != PT_JOB_DEAD;
+    bool wantShadow = false;
+    PtShadowRay sr;
+
+    if (live) {
+        PtRayStackSlot* s = f.stack + slot;
+        const uint4* hp = (const uint4*)(f.hitRecs + j);
+        uint4 h0 = hp[0], h1 = hp[1];
+        const int32_t i1 = (int32_t)h0.y, i2 = (int32_t)h0.z, i3 = (int32_t)h0.w;
+        if (i1 < 0) {                                                          /* trace.comp:192-196; the job ends here */
+            s->prob = 0;
+            f.jobs[j] = PT_JOB_DEAD;
+        } else {
+            const float t = __uint_as_float(h0.x);
+            const h16 bx = lo16(h1.x), by = hi16(h1.x), bz = lo16(h1.y);
+            const uint32_t origBvhId = h1.z;
+            const float4* sp = (const float4*)s;
+            float4 s0 = sp[0], s1 = sp[1];
+            F3 rd = { s0.x, s0.y, s0.z }, ro = { s1.x, s1.y, s1.z };
+            Rng rng; rng.rnd = __float_as_uint(s0.w);
+            const uint32_t currentDepth = __float_as_uint(s1.w);
+            F3 hitPos = { t * rd.x + ro.x, t * rd.y + ro.y, t * rd.z + ro.z };    /* trace.comp:198 */
+
+            /* shadeHit, trace.comp:58-163 */
+            const uint4* ap = (const uint4*)f.aux;
+            uint4 a1 = ap[i1], a2 = ap[i2], a3 = ap[i3];
+            const h16 inv255 = (h16)1.0f / (h16)255.0f;
+            h16 albedo[4];
+            for (int k = 0; k < 4; k++) {
+                h16 c1 = (h16)(float)((a1.w >> (8 * k)) & 0xFF) * inv255;
+                h16 c2 = (h16)(float)((a2.w >> (8 * k)) & 0xFF) * inv255;
+                h16 c3 = (h16)(float)((a3.w >> (8 * k)) & 0xFF) * inv255;
+                albedo[k] = (bx * c1 + by * c2) + bz * c3;
+            }
+            H3 n1 = { (h16)__uint_as_float(a1.x), (h16)__uint_as_float(a1.y), (h16)__uint_as_float(a1.z) };
+            H3 n2 = { (h16)__uint_as_float(a2.x), (h16)__uint_as_float(a2.y), (h16)__uint_as_float(a2.z) };
+            H3 n3 = { (h16)__uint_as_float(a3.x), (h16)__uint_as_float(a3.y), (h16)__uint_as_float(a3.z) };
+            H3 normal = hadd3(hadd3(hscale(bx, n1), hscale(by, n2)), hscale(bz, n3));
+            const h16 g = (h16)2.2f;
+            for (int k = 0; k < 3; k++) albedo[k] = (h16)powf((float)albedo[k], (float)g);
+            H3 rd16 = f2h3(rd);
+            if ((float)hdot(normal, rd16) > 0.0f) normal = { -normal.x, -normal.y, -normal.z };
+
+            float coinFlip = rng.getRandF();
+            h16 falloff; F3 lightDir; H3 lightRadiance; float lightMaxT;
+            if (coinFlip < 0.5f) {                                             /* trace.comp:85-105 */
+                const float4* lp = (const float4*)f.lights;
+                float4 l0 = lp[0], l1 = lp[1];
+                F3 posDiff = fsub({ l0.x, l0.y, l0.z }, hitPos);
+                float dist = __builtin_sqrtf(fdot(posDiff, posDiff));
+                lightDir = { posDiff.x / dist, posDiff.y / dist, posDiff.z / dist };
+                lightMaxT = dist - 0.00005f;
+                lightRadiance = { (h16)l1.x, (h16)l1.y, (h16)l1.z };
+                falloff = (h16)(1.0f / (dist * dist + 1.0f)) * hmax16((h16)0.0f, hdot(normal, f2h3(lightDir)));
+            } else {                                                           /* trace.comp:106-121 */
+                h16 gx, gy; WeylNth(rng.getRand(), gx, gy);
+                lightDir = h2f3(to_coord_space(normal, cosineHemisphere(gx, gy)));
+                lightMaxT = 1000.0f;
+                lightRadiance = { (h16)f.c.ambientRadiance[0], (h16)f.c.ambientRadiance[1], (h16)f.c.ambientRadiance[2] };
+                falloff = (h16)1.0f;
+            }
+            sr.o[0] = hitPos.x; sr.o[1] = hitPos.y; sr.o[2] = hitPos.z; sr.max_t = lightMaxT;
+            sr.d[0] = lightDir.x; sr.d[1] = lightDir.y; sr.d[2] = lightDir.z; sr.origBvhId = origBvhId;
+            sr.slot = slot; sr._pad[0] = sr._pad[1] = sr._pad[2] = 0;
+            wantShadow = true;
+
+            /* the contribution if the light sample is visible; the shadow pass clears it otherwise (trace.comp:123-130) */
+            h16 wIn[3];
+            const h16 lr[3] = { lightRadiance.x, lightRadiance.y, lightRadiance.z };
+            if ((float)albedo[3] > 0.5f) {
+                for (int k = 0; k < 3; k++) wIn[k] = (((h16)2.0f * falloff) * albedo[k]) * lr[k];
+            } else {
+                h16 ind = (h16)(fdot(lightDir, rd) > 0.995f ? 1.0f : 0.0f);
+                for (int k = 0; k < 3; k++) wIn[k] = ((h16)2.0f * ind) * lr[k];
+            }
+
+            h16 gx, gy; WeylNth(rng.getRand(), gx, gy);                        /* trace.comp:133-134 */
+            F3 nextDir = h2f3(to_coord_space(normal, cosineHemisphere(gx, gy)));
+            h16 prob;
+            bool cont = true;
+            if ((float)albedo[3] < 0.5f) {                                     /* trace.comp:136-149: ior is always 1.3 */
+                const h16 eta = (h16)1.3f;
+                H3 I = rd16, N = normal;
+                h16 d = hdot(N, I);
+                h16 k = (h16)1.0f - (eta * eta) * ((h16)1.0f - d * d);
+                H3 refr;
+                if ((float)k < 0.0f) refr = { (h16)0.0f, (h16)0.0f, (h16)0.0f };
+                else refr = hsub3(hscale(eta, I), hscale(eta * d + hsqrt16(k), N));
+                nextDir = h2f3(refr);
+                if (nextDir.x == 0.0f && nextDir.y == 0.0f && nextDir.z == 0.0f) nextDir = h2f3(hsub3(I, hscale((h16)2.0f * d, N)));
+                for (int q = 0; q < 4; q++) albedo[q] = hsqrt16(albedo[q]);
+                prob = (h16)1.0f;
+            } else {                                                           /* trace.comp:150-154 */
+                prob = (h16)1.0f / (h16)0.7f;
+                if (rng.getRandF() > 0.7f) cont = false;
+            }
+
+            if (cont && currentDepth != f.c.numRays - 1) {                     /* trace.comp:212-223 */
+                float4* np = (float4*)(s + 1);
+                np[0] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(rng.rnd));
+                np[1] = make_float4(hitPos.x, hitPos.y, hitPos.z, __uint_as_float(currentDepth + 1));
+                ((uint2*)(s + 1))[4] = make_uint2(0u, 0u);                     /* hitAlbedo = 0 */
+                f.jobs[j] = slot + 1;
+            } else {                                                           /* trace.comp:224-227 */
+                f.jobs[j] = PT_JOB_DEAD;
+                if (f.zeroNextSlot && currentDepth != f.c.numRays - 1) (s + 1)->prob = 0;
+            }
+            s->randState = rng.rnd;                                            /* trace.comp:229-232 */
+            uint4 o;
+            o.x = (uint32_t)hbits(albedo[0]) | ((uint32_t)hbits(albedo[1]) << 16);
+            o.y = (uint32_t)hbits(albedo[2]) | ((uint32_t)hbits(albedo[3]) << 16);
+            o.z = (uint32_t)hbits(wIn[0]) | ((uint32_t)hbits(wIn[1]) << 16);
+            o.w = (uint32_t)hbits(wIn[2]) | ((uint32_t)hbits(prob) << 16);
+            ((uint4*)s)[2] = o;
+        }
+    }
+
+    /* wave-aggregated append to the shadow-ray queue, and the live-job count */
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(wantShadow);
+    if (m) {
+        int leader = __ffsll((unsigned long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(f.ctr + CTR_NSHADOW, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (wantShadow) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            const uint4* src = (const uint4*)&sr;
+            uint4* dst = (uint4*)(f.shadowRays + base + rank);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+        }
+    }
+    uint64_t lm = __ballot(live);
+    if (lm && lane == __ffsll((unsigned long long)lm) - 1) atomicAdd(f.ctr + CTR_LIVE, (uint32_t)__popcll(lm));
+    (void)depthIndex;
+}
+
+/* Records the ray counts of one depth; one thread. */
+__global__ void k_record_counts(FrameArgs f, uint32_t depthIndex)
+{
+    f.rayCounts[2 * depthIndex] += f.ctr[CTR_LIVE];
+    f.rayCounts[2 * depthIndex + 1] += f.ctr[CTR_NSHADOW];
+}
+
+/* Stream compaction of the job list (the role of raysort.comp:23-55, over the whole list instead of
+ * per 256-wide row segment; the order of jobs does not influence any result). */
+__global__ __launch_bounds__(256) void k_compact(FrameArgs f)
+{
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t njobs = f.ctr[CTR_NJOBS];
+    uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
+    const bool live = slot != PT_JOB_DEAD;
+    const int lane = threadIdx.x & 63;
+    uint64_t m = __ballot(live);
+    if (!m) return;
+    int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(f.ctr + CTR_COMPACT_OUT, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (live) {
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        f.jobsOut[base + rank] = slot;
+    }
+}
+__global__ void k_compact_finish(FrameArgs f) { f.ctr[CTR_NJOBS] = f.ctr[CTR_COMPACT_OUT]; }
+
+/* composite.frag:30-55 */
+__global__ __launch_bounds__(256) void k_resolve(FrameArgs f)
+{
+    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= f.W * f.H) return;
+    const PtRayStackSlot* s = f.stack + (size_t)pix * f.c.numRays;
+    float L[3] = { 0, 0, 0 };
+    for (int depth = (int)f.c.numRays - 1; depth >= 0; depth--) {
+        uint4 q = ((const uint4*)(s + depth))[2];
+        float prob = (float)hi16(q.w);
+        if (prob > 0.0f) {
+            float w[3] = { (float)lo16(q.z), (float)hi16(q.z), (float)lo16(q.w) };
+            float al[3] = { (float)lo16(q.x), (float)hi16(q.x), (float)lo16(q.y) };
+            for (int k = 0; k < 3; k++) { L[k] *= prob; L[k] += w[k]; L[k] *= al[k]; }
+        } else {
+            L[0] = L[1] = L[2] = 0.0f;
+        }
+    }
+    uint2 cur;
+    cur.x = (uint32_t)hbits((h16)L[0]) | ((uint32_t)hbits((h16)L[1]) << 16);
+    cur.y = (uint32_t)hbits((h16)L[2]) | ((uint32_t)hbits((h16)1.0f) << 16);
+    f.current[pix] = cur;
+    float4 acc = f.accumulation[pix];
+    acc.x += L[0]; acc.y += L[1]; acc.z += L[2]; acc.w += 1.0f;
+    f.accumulation[pix] = acc;
+}
+
+/* Synthetic incoherent rays for the traversal microbench: five 24-bit uniforms per ray from
+ * successive splitmix64 outputs; origin uniform in the box, direction uniform on the sphere. */
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s)
+{
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_generate_rays(PtRay* rays, uint64_t seed, uint64_t first, uint64_t n, float ax, float ay, float az,
+                                                       float bx, float by, float bz)
+{
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + (first + i) * 0x9E3779B97F4A7C15ull;
+    float u[5];
+    for (int k = 0; k < 5; k++) u[k] = (float)(splitmix64(s) >> 40) * (1.0f / 16777216.0f);
+    float z = 1.0f - 2.0f * u[3], phi = 6.283185307179586f * u[4];
+    float rr = __builtin_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float4 q0 = make_float4(ax + (bx - ax) * u[0], ay + (by - ay) * u[1], az + (bz - az) * u[2], 0.001f);
+    float4 q1 = make_float4(rr * cosf(phi), rr * sinf(phi), z, 100000.0f);
+    float4* p = (float4*)(rays + i);
+    p[0] = q0; p[1] = q1;
+}

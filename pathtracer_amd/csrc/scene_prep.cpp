@@ -1,0 +1,171 @@
+/*
+ * scene_prep.cpp — host-side passes that run after the BVH build and before upload:
+ * the flattening pass (threaded 32 B nodes -> 64 B two-child records + inline triangle records)
+ * and the per-frame constants block.
+ */
+#include "../../include/ptcore.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#pragma STDC FP_CONTRACT OFF
+
+namespace {
+
+inline uint16_t f16_bits(float x)
+{
+    _Float16 h = (_Float16)x;      /* round-to-nearest-even, subnormals kept: the conversion f16vec3() performs */
+    uint16_t u; memcpy(&u, &h, 2); return u;
+}
+
+/* The ray-independent part of intersectBBox (reference intersections.glsl:3-5):
+ * c = (a + b) * 0.5f, hA = f16(a - c), hB = f16(b - c). */
+inline void digest_box(const PtBVHNode& n, float c[3], uint16_t h[6])
+{
+    for (int k = 0; k < 3; k++) {
+        c[k] = (n.a[k] + n.b[k]) * 0.5f;
+        h[k] = f16_bits(n.a[k] - c[k]);
+        h[3 + k] = f16_bits(n.b[k] - c[k]);
+    }
+}
+
+void set_err(char* err, size_t n, const char* msg) { if (err && n) snprintf(err, n, "%s", msg); }
+
+}  // namespace
+
+extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
+                                     uint32_t num_triangles, PtNode2* nodes2, PtTri* tris, float* root_box, uint32_t* max_stack,
+                                     char* err, size_t err_len)
+{
+    if (!nodes || !positions || !indices || !tris || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh: null argument"); return -1; }
+    if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
+
+    /* interior rank of every reference node (pre-order is kept, so a left child is rank+1 when interior) */
+    std::vector<uint32_t> rank(num_nodes);
+    uint32_t ni = 0;
+    for (uint32_t i = 0; i < num_nodes; i++) {
+        if (nodes[i].right > 0) {
+            if ((uint32_t)nodes[i].right >= num_nodes || i + 1 >= num_nodes) { set_err(err, err_len, "pt_flatten_bvh: child index out of range"); return -3; }
+            rank[i] = ni++;
+        } else {
+            uint32_t off = (uint32_t)(-nodes[i].right);
+            if (off % 3 != 0 || off / 3 >= num_triangles) { set_err(err, err_len, "pt_flatten_bvh: leaf offset out of range"); return -3; }
+            rank[i] = off / 3;
+        }
+    }
+    if (ni != num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: interior count is not T-1"); return -2; }
+
+    auto child_ref = [&](uint32_t i) { return nodes[i].right > 0 ? rank[i] : (PT_LEAF_BIT | rank[i]); };
+
+    for (uint32_t i = 0; i < num_nodes; i++) {
+        const PtBVHNode& n = nodes[i];
+        if (n.right > 0) {
+            PtNode2& o = nodes2[rank[i]];
+            memset(&o, 0, sizeof(o));
+            digest_box(nodes[i + 1], o.cL, o.hL);
+            digest_box(nodes[n.right], o.cR, o.hR);
+            o.left = child_ref(i + 1);
+            o.right = child_ref((uint32_t)n.right);
+            o.refIndex = i;
+        } else {
+            uint32_t t = rank[i];
+            PtTri& o = tris[t];
+            memset(&o, 0, sizeof(o));
+            uint32_t i1 = indices[3 * (size_t)t], i2 = indices[3 * (size_t)t + 1], i3 = indices[3 * (size_t)t + 2];
+            const float* p1 = positions + 4 * (size_t)i1; const float* p2 = positions + 4 * (size_t)i2; const float* p3 = positions + 4 * (size_t)i3;
+            for (int k = 0; k < 3; k++) { o.p1[k] = p1[k]; o.e1[k] = p2[k] - p1[k]; o.e2[k] = p3[k] - p1[k]; }   /* intersections.glsl:34-35 */
+            o.i1 = (int32_t)i1; o.i2 = (int32_t)i2; o.i3 = (int32_t)i3;
+            o.refLeaf = i;
+            o.flags = (i == num_nodes - 1) ? 1u : 0u;
+        }
+    }
+    if (root_box) { for (int k = 0; k < 3; k++) { root_box[k] = nodes[0].a[k]; root_box[3 + k] = nodes[0].b[k]; } }
+
+    if (max_stack) {
+        /* depth of the deepest node = the most entries a depth-first walk can have pending */
+        uint32_t deepest = 0;
+        std::vector<uint32_t> st = { 0 }, dp = { 0 };
+        while (!st.empty()) {
+            uint32_t i = st.back(), d = dp.back(); st.pop_back(); dp.pop_back();
+            if (d > deepest) deepest = d;
+            if (nodes[i].right > 0) { st.push_back((uint32_t)nodes[i].right); dp.push_back(d + 1); st.push_back(i + 1); dp.push_back(d + 1); }
+        }
+        *max_stack = deepest;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Constants block — the values PathTracer.cpp:731-750 writes: glm::lookAt (right-handed),
+ * glm::perspective(60 deg, W/H, 0.01, 256) with [1][1] negated, and their inverses.
+ * ---------------------------------------------------------------------------------------- */
+namespace {
+
+struct V3 { float x, y, z; };
+inline float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross3(V3 a, V3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline V3 norm3(V3 v) { float s = 1.0f / sqrtf(dot3(v, v)); return { v.x * s, v.y * s, v.z * s }; }
+
+/* column-major 4x4 inverse by cofactors */
+void invert4(const float* m, float* out)
+{
+    float inv[16];
+    inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+    float r = 1.0f / det;
+    for (int i = 0; i < 16; i++) out[i] = inv[i] * r;
+}
+
+}  // namespace
+
+extern "C" PT_API void pt_fill_constants(PtShaderConstants* c, uint32_t width, uint32_t height, const float focus_center[3],
+                                         float orbit_height, float orbit_radius, float orbit_angle, uint32_t num_lights,
+                                         uint32_t num_triangles, uint32_t frame_index, uint32_t num_rays, uint32_t num_bvh_nodes,
+                                         const float ambient[3])
+{
+    memset(c, 0, sizeof(*c));
+    V3 centre = { focus_center[0], focus_center[1], focus_center[2] };
+    V3 eye = { cosf(orbit_angle) * orbit_radius + centre.x, orbit_height + centre.y, sinf(orbit_angle) * orbit_radius + centre.z };   /* :734 */
+    V3 f = norm3({ centre.x - eye.x, centre.y - eye.y, centre.z - eye.z });
+    V3 s = norm3(cross3(f, { 0, 1, 0 }));
+    V3 u = cross3(s, f);
+    float* v = c->viewMtx;
+    v[0] = s.x; v[4] = s.y; v[8] = s.z;
+    v[1] = u.x; v[5] = u.y; v[9] = u.z;
+    v[2] = -f.x; v[6] = -f.y; v[10] = -f.z;
+    v[12] = -dot3(s, eye); v[13] = -dot3(u, eye); v[14] = dot3(f, eye); v[15] = 1.0f;
+
+    const float fovy = 60.0f * 0.01745329251994329576923690768489f, zNear = 0.01f, zFar = 256.0f;                                     /* :735 */
+    float aspect = (float)width / (float)height;
+    float th = tanf(fovy / 2.0f);
+    float* p = c->projMtx;
+    p[0] = 1.0f / (aspect * th);
+    p[5] = -(1.0f / th);                                                                                                              /* :737 */
+    p[10] = -(zFar + zNear) / (zFar - zNear);
+    p[11] = -1.0f;
+    p[14] = -(2.0f * zFar * zNear) / (zFar - zNear);
+
+    invert4(c->viewMtx, c->viewInvMtx);                                                                                               /* :739-740 */
+    invert4(c->projMtx, c->projInvMtx);
+    c->viewportSize[0] = (float)width; c->viewportSize[1] = (float)height;
+    c->numLights = num_lights; c->numTriangles = num_triangles; c->frameIndex = frame_index;
+    c->numRays = num_rays; c->numBVHNodes = num_bvh_nodes;
+    c->ambientRadiance[0] = ambient[0]; c->ambientRadiance[1] = ambient[1]; c->ambientRadiance[2] = ambient[2];
+}

@@ -1,0 +1,371 @@
+/*
+ * trace_kernels.h — BVH traversal + ray/triangle intersection kernels for gfx950.
+ *
+ * Two families, both one ray per lane of a 64-wide wavefront, both persistent: a launch is
+ * sized to the machine (workgroups per CU x CUs) and every wavefront keeps pulling rays from one
+ * global counter until the pool is empty, refilling its idle lanes in batches so that a lane
+ * whose ray ended early does not idle for the rest of its wavefront's longest ray.
+ *
+ *  k_trace_ref   walks the reference's threaded 32 B node array exactly as traceRay does
+ *                (reference intersections.glsl:57-115): no stack, one dependent 32 B fetch per
+ *                visit, two more dependent fetches per leaf.  Kept as the on-device restatement
+ *                and for the subgroup-vote ("SPECULATIVE") build of trace.comp.
+ *
+ *  k_trace_flat  walks the flattened layout: one 64 B record per step - either an interior
+ *                record holding both children's pre-digested boxes or a leaf record holding the
+ *                triangle inline - so a step is one line fetch followed by either two box tests
+ *                or one triangle test.  Pending siblings wait on a short per-lane stack in LDS
+ *                (entry e of lane l at [e][l]: conflict-free for any mix of stack depths), with
+ *                the static part of their box verdict already decided and the max_t part
+ *                re-checked when they are popped, which makes the walk visit exactly the nodes
+ *                the reference visits, in the same order.  ORDERED = true descends into the
+ *                nearer child first instead.
+ */
+#pragma once
+#include "../../include/ptcore.h"
+#include "device_math.h"
+
+#pragma clang fp contract(off)
+
+#define PT_STACK_LDS 16          /* per-lane stack entries held in LDS; deeper entries spill to global memory */
+#define PT_WAVES_PER_BLOCK 4
+#define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
+
+/* Result of a closest-hit walk as the shade stage consumes it, 32 B. */
+struct PtHitRec {
+    float    t;
+    int32_t  i1, i2, i3;         /* -1: miss */
+    uint16_t bary[3];            /* f16(gamma, alpha, beta), intersections.glsl:49 */
+    uint16_t _pad0;
+    uint32_t origBvhId;          /* what traceRay leaves in r.origBvhId (intersections.glsl:113) */
+    uint32_t _pad1;
+};
+
+/* A next-event-estimation ray, 48 B (trace.comp:95-100 / 111-116). */
+struct PtShadowRay {
+    float    o[3]; float max_t;
+    float    d[3]; uint32_t origBvhId;
+    uint32_t slot;               /* ray-stack slot whose wIn is cleared when the ray is occluded */
+    uint32_t _pad[3];
+};
+
+enum { MODE_RAYS = 0, MODE_JOBS = 1, MODE_SHADOW = 2 };
+
+struct TraceArgs {
+    /* reference layout */
+    const PtBVHNode* nodes;  uint32_t numNodes;
+    const uint32_t*  indices;
+    const float4*    positions;
+    /* flattened layout */
+    const uint4*     nodes2;
+    const uint4*     tris;
+    float            rootC[3]; uint16_t rootH[6]; uint32_t rootRef;
+    uint2*           overflow;       /* [entry][global lane] spill area of the LDS stacks */
+    uint32_t         overflowEntries;
+    /* work */
+    uint32_t*        fetchCounter;   /* next unclaimed ray */
+    const uint32_t*  countPtr;       /* number of rays, read on the device (nullptr: use count) */
+    uint64_t         count;
+    uint32_t         refillMin;      /* refill a wavefront when this many lanes are idle */
+    /* MODE_RAYS */
+    const PtRay*     rays;  PtHit* hits;
+    /* MODE_JOBS */
+    const uint32_t*  jobs;  PtRayStackSlot* stack;  PtHitRec* hitRecs;
+    /* MODE_SHADOW */
+    const PtShadowRay* shadowRays;
+    /* counting build */
+    unsigned long long* stats;       /* {box tests, triangle tests, records fetched, rays} */
+};
+
+/* ---- per-mode ray fetch / result store ------------------------------------------------------- */
+
+template <int MODE>
+__device__ __forceinline__ bool load_ray(const TraceArgs& a, uint64_t id, RayRegs& r, uint32_t& exclude, uint32_t& tag)
+{
+    if (MODE == MODE_RAYS) {
+        const float4* p = (const float4*)(a.rays + id);
+        float4 q0 = p[0], q1 = p[1];
+        r.o = { q0.x, q0.y, q0.z }; r.min_t = q0.w;
+        ray_set_dir(r, { q1.x, q1.y, q1.z }); r.max_t = q1.w;
+        exclude = 0; tag = 0;
+        return true;
+    } else if (MODE == MODE_JOBS) {
+        uint32_t slot = a.jobs[id];
+        if (slot == PT_JOB_DEAD) return false;
+        const float4* p = (const float4*)(a.stack + slot);                  /* trace.comp:185-190 */
+        float4 q0 = p[0], q1 = p[1];
+        ray_set_dir(r, { q0.x, q0.y, q0.z });
+        r.o = { q1.x, q1.y, q1.z };
+        r.min_t = 0.001f; r.max_t = 100000.0f;
+        exclude = 0; tag = slot;
+        return true;
+    } else {
+        const float4* p = (const float4*)(a.shadowRays + id);
+        float4 q0 = p[0], q1 = p[1];
+        uint32_t slot = a.shadowRays[id].slot;
+        r.o = { q0.x, q0.y, q0.z }; r.max_t = q0.w;
+        ray_set_dir(r, { q1.x, q1.y, q1.z });
+        r.min_t = 0.001f;
+        exclude = __float_as_uint(q1.w); tag = slot;
+        return true;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, uint32_t tag, bool hit, float t, int32_t i1, int32_t i2, int32_t i3,
+                                             float alpha, float beta, float gamma, uint32_t origBvhId)
+{
+    if (MODE == MODE_RAYS) {
+        float4 o;
+        o.x = t;
+        o.y = __int_as_float(hit ? i1 : -1); o.z = __int_as_float(hit ? i2 : -1); o.w = __int_as_float(hit ? i3 : -1);
+        *(float4*)(a.hits + id) = o;
+    } else if (MODE == MODE_JOBS) {
+        uint4 o0, o1;
+        o0.x = __float_as_uint(t);
+        o0.y = (uint32_t)(hit ? i1 : -1); o0.z = (uint32_t)(hit ? i2 : -1); o0.w = (uint32_t)(hit ? i3 : -1);
+        o1.x = (uint32_t)hbits((h16)gamma) | ((uint32_t)hbits((h16)alpha) << 16);
+        o1.y = (uint32_t)hbits((h16)beta);
+        o1.z = origBvhId; o1.w = 0;
+        uint4* p = (uint4*)(a.hitRecs + id);
+        p[0] = o0; p[1] = o1;
+    } else {
+        if (hit) {      /* occluded: the light sample contributes nothing (trace.comp:123) */
+            PtRayStackSlot* s = a.stack + tag;
+            s->wIn[0] = 0; s->wIn[1] = 0; s->wIn[2] = 0;
+        }
+    }
+}
+
+/* Claims ids for the idle lanes of this wavefront from the global counter.  Wave-uniform call. */
+__device__ __forceinline__ uint64_t claim_ids(uint32_t* counter, bool idle, uint64_t idleMask, int nIdle, uint64_t& waveEnd)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0));
+    int leader = __ffsll((unsigned long long)idleMask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)nIdle);
+    base = __shfl(base, leader);
+    waveEnd = (uint64_t)base + (uint64_t)nIdle;
+    return idle ? (uint64_t)base + rank : ~0ull;
+}
+
+/* ---- reference-layout walk -------------------------------------------------------------------- */
+
+template <int MODE, bool ANYHIT, bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_ref(TraceArgs a)
+{
+    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    bool active = false, exhausted = false;
+    RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
+    uint32_t index = 0, hitIndex = 0; bool hit = false;
+    int32_t i1 = -1, i2 = -1, i3 = -1; float alpha = 0, beta = 0, gamma = 0;
+    unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+
+    for (;;) {
+        uint64_t idleMask = __ballot(!active);
+        int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && exhausted) break;
+        if (!exhausted && (nIdle >= (int)a.refillMin || nIdle == 64)) {
+            uint64_t waveEnd;
+            uint64_t nid = claim_ids(a.fetchCounter, !active, idleMask, nIdle, waveEnd);
+            if (waveEnd >= total) exhausted = true;
+            if (!active && nid < total) {
+                id = nid;
+                if (load_ray<MODE>(a, id, r, exclude, tag)) {
+                    active = true; index = 0; hitIndex = 0; hit = false; i1 = i2 = i3 = -1;
+                    if (COUNT) nRay++;
+                }
+            }
+        }
+        if (!active) continue;
+
+        /* one visit of the loop at intersections.glsl:64-111 */
+        bool done = false, ranOff = false;
+        const float4* np = (const float4*)(a.nodes + index);
+        float4 na = np[0], nb = np[1];
+        if (COUNT) { nBox++; nRec++; }
+        if (box_raw(r, na, nb)) {
+            int32_t right = __float_as_int(nb.w);
+            if (right <= 0 && (exclude == 0 || exclude != index)) {
+                uint32_t tri = (uint32_t)(-right) / 3u;
+                uint32_t v1 = a.indices[3 * tri], v2 = a.indices[3 * tri + 1], v3 = a.indices[3 * tri + 2];
+                float4 p1 = a.positions[v1], p2 = a.positions[v2], p3 = a.positions[v3];
+                if (COUNT) { nTri++; nRec += 4; }
+                float t, al, be, ga;
+                F3 P1 = { p1.x, p1.y, p1.z };
+                if (tri_test(r, P1, fsub({ p2.x, p2.y, p2.z }, P1), fsub({ p3.x, p3.y, p3.z }, P1), t, al, be, ga)) {
+                    r.max_t = t; alpha = al; beta = be; gamma = ga;
+                    i1 = (int32_t)v1; i2 = (int32_t)v2; i3 = (int32_t)v3;
+                    hit = true; hitIndex = index;
+                    if (ANYHIT) done = true;
+                }
+            }
+            index++;
+            if (index >= a.numNodes) { done = true; ranOff = true; }
+        } else {
+            index = (uint32_t)__float_as_int(na.w);
+            if (index == 0) done = true;
+        }
+        if (done) {
+            store_result<MODE>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, (ranOff && !(ANYHIT && hit)) ? hitIndex : 0u);
+            active = false;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
+    }
+}
+
+/* The SPECULATIVE build of trace.comp at depth 0 (intersections.glsl:73-77): one wavefront per
+ * 8x8 pixel tile, lane k at tile position (k % 8, k / 8); every lane follows the wavefront's vote,
+ * so all lanes share one node index. */
+__global__ __launch_bounds__(64) void k_trace_ref_speculative(TraceArgs a, uint32_t W, uint32_t H)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t x = blockIdx.x * 8 + (lane & 7), y = blockIdx.y * 8 + (lane >> 3);
+    const uint64_t id = (uint64_t)y * W + x;
+    RayRegs r; uint32_t exclude = 0, tag = 0;
+    bool live = (x < W && y < H) && load_ray<MODE_JOBS>(a, id, r, exclude, tag);
+    if (!live) return;      /* lanes without a job take no part in the vote (trace.comp:168) */
+    uint32_t index = 0, hitIndex = 0; bool hit = false, ranOff = false;
+    int32_t i1 = -1, i2 = -1, i3 = -1; float alpha = 0, beta = 0, gamma = 0;
+    while (index < a.numNodes) {
+        const float4* np = (const float4*)(a.nodes + index);
+        float4 na = np[0], nb = np[1];
+        bool pass = box_raw(r, na, nb);
+        if (__any(pass)) {
+            int32_t right = __float_as_int(nb.w);
+            if (right <= 0) {
+                uint32_t tri = (uint32_t)(-right) / 3u;
+                uint32_t v1 = a.indices[3 * tri], v2 = a.indices[3 * tri + 1], v3 = a.indices[3 * tri + 2];
+                float4 p1 = a.positions[v1], p2 = a.positions[v2], p3 = a.positions[v3];
+                float t, al, be, ga;
+                F3 P1 = { p1.x, p1.y, p1.z };
+                if (tri_test(r, P1, fsub({ p2.x, p2.y, p2.z }, P1), fsub({ p3.x, p3.y, p3.z }, P1), t, al, be, ga)) {
+                    r.max_t = t; alpha = al; beta = be; gamma = ga;
+                    i1 = (int32_t)v1; i2 = (int32_t)v2; i3 = (int32_t)v3;
+                    hit = true; hitIndex = index;
+                }
+            }
+            index++;
+            if (index >= a.numNodes) ranOff = true;
+        } else {
+            index = (uint32_t)__float_as_int(na.w);
+            if (index == 0) break;
+        }
+    }
+    store_result<MODE_JOBS>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, ranOff ? hitIndex : 0u);
+}
+
+/* ---- flattened-layout walk -------------------------------------------------------------------- */
+
+template <int MODE, bool ANYHIT, bool ORDERED, bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
+{
+    __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
+    __shared__ uint16_t sTmin[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
+    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+
+    bool active = false, exhausted = false;
+    RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
+    uint32_t cur = 0; int sp = 0;
+    bool hit = false, ranOff = false; uint32_t hitTri = 0;
+    float alpha = 0, beta = 0, gamma = 0;
+    unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+
+    const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
+    const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
+
+    for (;;) {
+        uint64_t idleMask = __ballot(!active);
+        int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && exhausted) break;
+        if (!exhausted && (nIdle >= (int)a.refillMin || nIdle == 64)) {
+            uint64_t waveEnd;
+            uint64_t nid = claim_ids(a.fetchCounter, !active, idleMask, nIdle, waveEnd);
+            if (waveEnd >= total) exhausted = true;
+            if (!active && nid < total) {
+                id = nid;
+                if (load_ray<MODE>(a, id, r, exclude, tag)) {
+                    if (COUNT) { nRay++; nBox++; }
+                    hit = false; ranOff = false; sp = 0;
+                    float ftmin;
+                    bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
+                    if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
+                    else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);      /* root box missed */
+                }
+            }
+        }
+        if (!active) continue;
+
+        /* one step: fetch the 64 B record `cur` names, then two box tests or one triangle test */
+        const bool leaf = (cur & PT_LEAF_BIT) != 0;
+        const uint4* rec = (leaf ? a.tris : a.nodes2) + (size_t)(cur & ~PT_LEAF_BIT) * 4;
+        uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        if (COUNT) nRec++;
+        bool needPop = true, done = false;
+
+        if (leaf) {
+            if (q3.y & 1u) ranOff = true;                                   /* the reference array's last node was entered */
+            if (exclude == 0 || exclude != q3.x) {                          /* intersections.glsl:81 */
+                if (COUNT) nTri++;
+                float t, al, be, ga;
+                F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
+                F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
+                F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
+                if (tri_test(r, p1, e1, e2, t, al, be, ga)) {
+                    r.max_t = t; alpha = al; beta = be; gamma = ga;
+                    hit = true; hitTri = cur & ~PT_LEAF_BIT;
+                    if (ANYHIT) { done = true; needPop = false; }
+                }
+            }
+        } else {
+            if (COUNT) nBox += 2;
+            float tminL, tminR;
+            bool sL = box_static(r, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
+                                 lo16(q0.w), hi16(q0.w), lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y), tminL);
+            bool sR = box_static(r, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
+                                 lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w), tminR);
+            bool pL = sL && r.max_t > tminL, pR = sR && r.max_t > tminR;
+            uint32_t first = q3.x, second = q3.y; float tminSecond = tminR;
+            bool pFirst = pL, pSecond = pR;
+            if (ORDERED && pL && pR && tminR < tminL) { first = q3.y; second = q3.x; tminSecond = tminL; }
+            if (pSecond && pFirst) {
+                /* push the sibling with its tmin; `max_t > tmin` is re-evaluated at pop time */
+                uint16_t tb = hbits((h16)tminSecond);                       /* exact: tmin came from an fp16 */
+                if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = second; sTmin[wave][sp][lane] = tb; }
+                else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, tb);
+                sp++;
+                cur = first; needPop = false;
+            } else if (pFirst) { cur = first; needPop = false; }
+            else if (pSecond) { cur = second; needPop = false; }
+        }
+
+        while (needPop) {
+            if (sp == 0) { done = true; break; }
+            sp--;
+            uint32_t ref; uint16_t tb;
+            if (sp < PT_STACK_LDS) { ref = sRef[wave][sp][lane]; tb = sTmin[wave][sp][lane]; }
+            else { uint2 e = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = e.x; tb = (uint16_t)e.y; }
+            if (r.max_t > (float)hfrombits(tb)) { cur = ref; needPop = false; }
+        }
+
+        if (done) {
+            int32_t i1 = -1, i2 = -1, i3 = -1; uint32_t orig = 0;
+            if (hit && MODE != MODE_SHADOW) {
+                const uint32_t* tr = (const uint32_t*)(a.tris + (size_t)hitTri * 4);
+                i1 = (int32_t)tr[3]; i2 = (int32_t)tr[7]; i3 = (int32_t)tr[11];
+                if (MODE == MODE_JOBS && ranOff) orig = tr[12];
+            }
+            store_result<MODE>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, orig);
+            active = false;
+        }
+    }
+    if (COUNT) {
+        atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
+    }
+}

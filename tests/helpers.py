@@ -1,0 +1,48 @@
+"""Shared helpers of the test-suite: synthetic rays, oracle scene construction."""
+import numpy as np
+
+import oracle
+import pathtracer_amd as pt
+
+
+def random_rays(root_a, root_b, n, seed, inside=True):
+    """Incoherent rays: origin uniform in the box, direction uniform on the sphere (numpy twin of pt_generate_rays)."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=pt.RAY_DT)
+    a, b = np.asarray(root_a, dtype=np.float32), np.asarray(root_b, dtype=np.float32)
+    rays["o"] = a + (b - a) * rng.random((n, 3), dtype=np.float32)
+    if not inside:
+        rays["o"] = (a + b) * 0.5 + (rays["o"] - (a + b) * 0.5) * 2.5
+    z = 1 - 2 * rng.random(n); phi = 2 * np.pi * rng.random(n); r = np.sqrt(np.maximum(0, 1 - z * z))
+    rays["d"] = np.stack([r * np.cos(phi), r * np.sin(phi), z], 1).astype(np.float32)
+    rays["min_t"] = 0.001
+    rays["max_t"] = 1e5
+    return rays
+
+
+def camera_rays(W, H, eye=(3.0, 0.5, 0.0), target=(0.0, 0.0, 0.0), fov_deg=60.0):
+    """Primary-like rays from the reference's default camera position (PathTracer.cpp:109-112)."""
+    eye = np.asarray(eye, dtype=np.float64); target = np.asarray(target, dtype=np.float64)
+    f = target - eye; f /= np.linalg.norm(f)
+    s = np.cross(f, [0, 1, 0]); s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    th = np.tan(np.radians(fov_deg) / 2)
+    xs = ((np.arange(W) + 0.5) / W * 2 - 1) * th * (W / H)
+    ys = ((np.arange(H) + 0.5) / H * 2 - 1) * th
+    X, Y = np.meshgrid(xs, ys)
+    d = f[None, None] + X[..., None] * s + Y[..., None] * u
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    rays = np.zeros(W * H, dtype=pt.RAY_DT)
+    rays["o"] = eye.astype(np.float32)
+    rays["d"] = d.reshape(-1, 3).astype(np.float32)
+    rays["min_t"] = 0.001
+    rays["max_t"] = 1e5
+    return rays
+
+
+def oracle_scene(model, lights=None, blue_noise=None):
+    return oracle.Scene(model["positions"], model["aux"], model["indices"], model["nodes"], lights, blue_noise)
+
+
+def upload(ctx, model, lights=None, blue_noise=None):
+    ctx.upload_scene(model["positions"], model["aux"], model["indices"], model["nodes"], lights, blue_noise)

@@ -1,0 +1,144 @@
+"""Parity of the HIP traversal kernels with the CPU oracle on identical rays, through the C ABI.
+
+Bars: hit vertex triples identical (the kernels restate the reference's fp16 box test and fp32
+triangle test operation by operation, so the reference-order layouts are expected to agree bit for
+bit, t included); the near-child-first layout may differ on rays where the fp16 box test of the
+closest leaf is on the edge, and must stay within 1e-4 of all rays (the bar of 99.99 % agreement).
+"""
+import numpy as np
+import pytest
+
+import helpers
+import pathtracer_amd as pt
+from pathtracer_amd import core
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, model, osc, rays, any_hit, traversal, exact=True):
+    ctx.set_option(core.OPT_TRAVERSAL, traversal)
+    hits = ctx.trace_rays(rays, any_hit=any_hit)
+    ref = osc.trace(rays, any_hit=any_hit)
+    hit_g, hit_o = hits["i1"] >= 0, ref["i1"] >= 0
+    if any_hit and traversal == core.TRAVERSAL_FLAT_ORDERED:
+        # any-hit only promises "some hit iff the reference finds one"
+        assert np.array_equal(hit_g, hit_o)
+        return 0.0
+    same = (hits["i1"] == ref["i1"]) & (hits["i2"] == ref["i2"]) & (hits["i3"] == ref["i3"])
+    if exact:
+        assert same.all(), f"{(~same).sum()} of {len(rays)} rays differ"
+        assert np.array_equal(hits["t"].view(np.uint32), ref["t"].view(np.uint32)), "t differs bitwise"
+    else:
+        frac = float((~same).mean())
+        assert frac <= 1e-4, f"{frac:.2e} of rays differ"
+        both = same & hit_o
+        rel = np.abs(hits["t"][both] - ref["t"][both]) / np.maximum(np.abs(ref["t"][both]), 1e-30)
+        assert rel.max() <= 1e-5
+    return float((~same).mean())
+
+
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT])
+@pytest.mark.parametrize("any_hit", [False, True])
+def test_bunny_random_rays_exact(gpu_ctx, oracle_lib, bunny, traversal, any_hit):
+    helpers.upload(gpu_ctx, bunny)
+    osc = helpers.oracle_scene(bunny)
+    rays = helpers.random_rays(bunny["nodes"][0]["a"], bunny["nodes"][0]["b"], 200_000, seed=5)
+    _check(gpu_ctx, bunny, osc, rays, any_hit, traversal)
+
+
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT])
+def test_bunny_camera_rays_exact(gpu_ctx, oracle_lib, bunny, traversal):
+    helpers.upload(gpu_ctx, bunny)
+    osc = helpers.oracle_scene(bunny)
+    rays = helpers.camera_rays(640, 360)
+    _check(gpu_ctx, bunny, osc, rays, False, traversal)
+
+
+@pytest.mark.parametrize("model_name", ["monkey", "courtyard_small"])
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT])
+def test_other_scenes_exact(gpu_ctx, oracle_lib, request, model_name, traversal):
+    model = request.getfixturevalue(model_name)
+    helpers.upload(gpu_ctx, model)
+    osc = helpers.oracle_scene(model)
+    a, b = model["nodes"][0]["a"], model["nodes"][0]["b"]
+    rays = np.concatenate([helpers.random_rays(a, b, 100_000, seed=9), helpers.random_rays(a, b, 50_000, seed=10, inside=False)])
+    _check(gpu_ctx, model, osc, rays, False, traversal)
+    _check(gpu_ctx, model, osc, rays, True, traversal)
+
+
+@pytest.mark.parametrize("model_name", ["bunny", "monkey", "courtyard_small"])
+def test_ordered_traversal_within_bar(gpu_ctx, oracle_lib, request, model_name):
+    model = request.getfixturevalue(model_name)
+    helpers.upload(gpu_ctx, model)
+    osc = helpers.oracle_scene(model)
+    a, b = model["nodes"][0]["a"], model["nodes"][0]["b"]
+    rays = np.concatenate([helpers.random_rays(a, b, 200_000, seed=21), helpers.camera_rays(640, 360)])
+    frac = _check(gpu_ctx, model, osc, rays, False, core.TRAVERSAL_FLAT_ORDERED, exact=False)
+    print(f"{model_name}: near-first order differs from the reference order on {frac:.2e} of rays")
+    _check(gpu_ctx, model, osc, rays, True, core.TRAVERSAL_FLAT_ORDERED, exact=False)
+
+
+def test_stats_match_oracle_counts(gpu_ctx, oracle_lib, bunny):
+    """The counting build reports exactly the box and triangle tests the reference walk performs."""
+    helpers.upload(gpu_ctx, bunny)
+    osc = helpers.oracle_scene(bunny)
+    rays = helpers.random_rays(bunny["nodes"][0]["a"], bunny["nodes"][0]["b"], 50_000, seed=2)
+    _, cnt = osc.trace(rays, want_counters=True)
+    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT):
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
+        _, st = gpu_ctx.trace_rays(rays, want_stats=True)
+        assert int(st[3]) == len(rays)
+        assert int(st[1]) == int(cnt[1]), (trav, st, cnt)
+        assert int(st[0]) == int(cnt[0]), (trav, st, cnt)
+
+
+def test_edge_cases(gpu_ctx, oracle_lib, bunny):
+    helpers.upload(gpu_ctx, bunny)
+    osc = helpers.oracle_scene(bunny)
+    # empty input, one ray, a ragged count that is not a multiple of the wavefront, rays that miss the root box,
+    # axis-parallel rays (1/0 = inf in rcpD)
+    assert len(gpu_ctx.trace_rays(np.zeros(0, dtype=pt.RAY_DT))) == 0
+    rays = helpers.random_rays(bunny["nodes"][0]["a"], bunny["nodes"][0]["b"], 1000 + 37, seed=1)
+    rays["o"][:100] += 50.0
+    rays["d"][100:200] = (1.0, 0.0, 0.0)
+    rays["d"][200:300] = (0.0, -1.0, 0.0)
+    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT):
+        _check(gpu_ctx, bunny, osc, rays[:1], False, trav)
+        _check(gpu_ctx, bunny, osc, rays, False, trav)
+        _check(gpu_ctx, bunny, osc, rays, True, trav)
+
+
+def test_single_triangle_scene(gpu_ctx, oracle_lib):
+    pos = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1]], dtype=np.float32)
+    idx = np.array([[0, 1, 2]], dtype=np.uint32)
+    aux = np.zeros(3, dtype=pt.AUX_DT)
+    nodes, ridx, _ = pt.build_bvh(pos, idx)
+    model = dict(positions=pos, aux=aux, indices=ridx, nodes=nodes)
+    helpers.upload(gpu_ctx, model)
+    osc = helpers.oracle_scene(model)
+    rays = helpers.random_rays((-1, -1, -1), (1, 1, 1), 5000, seed=4)
+    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED):
+        _check(gpu_ctx, model, osc, rays, False, trav)
+
+
+def test_generated_rays_and_device_path(gpu_ctx, oracle_lib, bunny):
+    """pt_generate_rays + device-resident trace, checked against the oracle on the copied-back rays."""
+    helpers.upload(gpu_ctx, bunny)
+    osc = helpers.oracle_scene(bunny)
+    n = 1 << 18
+    d_rays, d_hits = gpu_ctx.alloc(n * 32), gpu_ctx.alloc(n * 16)
+    try:
+        gpu_ctx.generate_rays(d_rays, n)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        gpu_ctx.trace_rays_device(d_rays, n, d_hits)
+        rays = d_rays.to_host(pt.RAY_DT)
+        hits = d_hits.to_host(pt.HIT_DT)
+    finally:
+        d_rays.free(); d_hits.free()
+    a, b = bunny["nodes"][0]["a"], bunny["nodes"][0]["b"]
+    assert (rays["o"] >= a).all() and (rays["o"] <= b).all()
+    assert np.allclose(np.linalg.norm(rays["d"], axis=1), 1.0, atol=1e-5)
+    assert abs(rays["d"].mean(0)).max() < 0.01
+    ref = osc.trace(rays)
+    assert np.array_equal(hits, ref)
+    assert gpu_ctx.last_kernel_ms() > 0
