@@ -49,6 +49,14 @@ def _load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own ROCm runtime libraries under the same sonames as /opt/rocm's; whichever set is
+    # loaded first serves the whole process.  Loading torch's first keeps one consistent set when torch is
+    # used for torch.distributed later (a mixed set aborts at process exit).  PTCORE_NO_TORCH=1 skips this.
+    if os.environ.get("PTCORE_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise PtError(f"{path} is missing: build it with `python pathtracer_amd/build.py` (there is no CPU fallback)")

@@ -194,13 +194,24 @@ def courtyard(num_triangles, seed=7, extent=2.0):
     _cylinders(m, base, 0.035 * E, 0.45 * E, seg, stone)
     _boxes(m, base + np.array([0, 0.47 * E, 0]), (0.05 * E, 0.02 * E, 0.05 * E), stone)
 
-    # furniture: tables, chairs and pots, ~20 %
+    # furniture: tables with a bowl each, ~20 %.  Tables sit on a jittered grid so that no two overlap, and each
+    # has its own height: coplanar overlapping faces would make exact t-ties, which real scenes mostly avoid.
     nobj = max(1, int(0.20 * budget / (12 * 5 + 2 * 12 * 10)))
-    c = np.stack([rng.uniform(-0.6 * E, 0.6 * E, nobj), np.zeros(nobj), rng.uniform(-0.55 * E, 0.55 * E, nobj)], 1)
-    _boxes(m, c + np.array([0, 0.18, 0]), (0.16, 0.008, 0.16), wood)                       # table top
-    for dx, dz in ((-0.14, -0.14), (0.14, -0.14), (0.14, 0.14), (-0.14, 0.14)):
-        _boxes(m, c + np.array([dx, 0.09, dz]), (0.008, 0.09, 0.008), wood)                # legs
-    _spheres(m, c + np.array([0, 0.215, 0]), 0.03, 12, 10, cloth)                          # a bowl on each table
+    side = int(np.ceil(np.sqrt(nobj)))
+    cell = 1.2 * E / side
+    hw = min(0.16, 0.38 * cell)                                                            # half width of a table top
+    gx, gz = np.meshgrid(np.arange(side), np.arange(side), indexing="xy")
+    keep = rng.permutation(side * side)[:nobj]
+    jit = (rng.random((nobj, 2)) - 0.5) * (cell - 2.1 * hw)
+    c = np.stack([-0.6 * E + (gx.reshape(-1)[keep] + 0.5) * cell + jit[:, 0], 0.15 + 0.08 * rng.random(nobj),
+                  -0.6 * E + (gz.reshape(-1)[keep] + 0.5) * cell + jit[:, 1]], 1)          # c.y = height of the table top
+    up = np.array([0.0, 1.0, 0.0])
+    _boxes(m, c, (hw, 0.008, hw), wood)                                                    # table top
+    leg_h = (c[:, 1] - 0.008) * 0.5
+    for dx, dz in ((-0.85, -0.85), (0.85, -0.85), (0.85, 0.85), (-0.85, 0.85)):
+        lc = c.copy(); lc[:, 0] += dx * hw; lc[:, 2] += dz * hw; lc[:, 1] = leg_h
+        _boxes(m, lc, np.stack([np.full(nobj, 0.05 * hw), leg_h, np.full(nobj, 0.05 * hw)], 1), wood)   # legs
+    _spheres(m, c + up * (0.008 + 0.19 * hw), 0.19 * hw, 12, 10, cloth)                    # a bowl on each table
 
     # trees: trunk + foliage clouds; foliage takes what is left of the budget
     ntree = max(4, int(np.sqrt(budget) / 40))

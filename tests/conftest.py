@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:        # torch first: its bundled ROCm runtime then serves the whole process (see pathtracer_amd/core.py)
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

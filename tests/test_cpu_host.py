@@ -1,0 +1,205 @@
+"""CPU-side checks (no GPU): the C ABI loads and exports what include/ptcore.h declares, the PLY
+reader, the parallel BVH builder against the oracle's line-by-line restatement of BuildBVH, the
+flattening pass, and the constants block."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import plyio
+import pathtracer_amd as pt
+from pathtracer_amd import core
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = os.path.join(ROOT, "tests", "golden", "models")
+
+
+def test_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+    declared = set(re.findall(r"PT_API\s+[\w\s\*]+?\b(pt_\w+)\s*\(", hdr))
+    assert len(declared) >= 30
+    lib = C.CDLL(pt.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in ptcore.h but not exported"
+    assert declared == set(core._load()._pt_signatures), "python binding and header disagree"
+    assert b"gfx950" in core._load().pt_version()
+
+
+def test_context_needs_a_gpu_and_says_so():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pt.PtError) as e:
+        pt.PathTracer(0)
+    assert "no CPU path" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_struct_layouts_match_reference_contract():
+    # sizes and offsets of SURVEY's data contract (ShaderData.h:9-47, structures.glsl:35-72)
+    assert core.SLOT_DT.fields["randState"][1] == 12 and core.SLOT_DT.fields["rayOrigin"][1] == 16
+    assert core.SLOT_DT.fields["currentDepth"][1] == 28 and core.SLOT_DT.fields["hitAlbedo"][1] == 32
+    assert core.SLOT_DT.fields["wIn"][1] == 40 and core.SLOT_DT.fields["prob"][1] == 46
+    assert core.CONST_DT.fields["viewportSize"][1] == 256 and core.CONST_DT.fields["numLights"][1] == 272
+    assert core.CONST_DT.fields["numBVHNodes"][1] == 288 and core.CONST_DT.fields["ambientRadiance"][1] == 304
+    assert core.NODE_DT.fields["next"][1] == 12 and core.NODE_DT.fields["right"][1] == 28
+
+
+@pytest.mark.parametrize("name,nv,nt", [("CBbunny.ply", 14454, 28588), ("CBmonkey.ply", 11828, 5818)])
+def test_ply_reader_matches_numpy_reader(name, nv, nt):
+    pos, aux, idx = pt.load_ply(os.path.join(MODELS, name))
+    ref = plyio.read_ply(os.path.join(MODELS, name))
+    assert pos.shape == (nv, 4) and idx.shape == (nt, 3)
+    assert np.array_equal(pos, ref["positions"]) and np.array_equal(idx, ref["indices"])
+    assert np.array_equal(aux["normal"], ref["normals"]) and np.array_equal(aux["color"], ref["colors"])
+    assert (pos[:, 3] == 1).all()
+
+
+def test_ply_reader_ascii_and_errors(tmp_path):
+    p = tmp_path / "quad.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element face 1\nproperty list uchar uint vertex_indices\nend_header\n"
+                 "0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    pos, aux, idx = pt.load_ply(str(p))
+    assert idx.tolist() == [[0, 1, 2], [0, 2, 3]]          # fan triangulation
+    assert (aux["color"] == 255).all()
+    stub = tmp_path / "stub.ply"
+    stub.write_text("version https://git-lfs.github.com/spec/v1\noid sha256:00\nsize 1\n")
+    with pytest.raises(pt.PtError):
+        pt.load_ply(str(stub))
+    with pytest.raises(pt.PtError):
+        pt.load_ply(str(tmp_path / "missing.ply"))
+    bad = tmp_path / "bad.ply"
+    bad.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\n"
+                   "element face 1\nproperty list uchar uint vertex_indices\nend_header\n0 0 0\n3 0 1 2\n")
+    with pytest.raises(pt.PtError):
+        pt.load_ply(str(bad))
+
+
+def _check_bvh_invariants(nodes, ridx, pos):
+    T = ridx.shape[0]
+    N = nodes.shape[0]
+    assert N == 2 * T - 1
+    right, nxt = nodes["right"], nodes["next"]
+    leaves = right <= 0
+    assert leaves.sum() == T
+    # every triangle in exactly one leaf
+    assert sorted((-right[leaves] // 3).tolist()) == list(range(T))
+    assert nxt[0] == 0
+    # pre-order + skip links: walking with every box missed visits root, then ends
+    # children inside parents, leaf boxes contain their triangle (with the 6e-5 pad)
+    stack = [(0, 0)]
+    seen = 0
+    while stack:
+        i, nx = stack.pop()
+        seen += 1
+        assert nxt[i] == nx
+        if right[i] > 0:
+            l, r = i + 1, right[i]
+            for c in (l, r):
+                assert (nodes["a"][c] >= nodes["a"][i] - 1e-7).all() and (nodes["b"][c] <= nodes["b"][i] + 1e-7).all()
+            stack.append((r, nx)); stack.append((l, r))
+        else:
+            tri = pos[ridx[-right[i] // 3], :3]
+            assert (tri.min(0) - 6.1e-5 <= nodes["a"][i]).all() and (tri.min(0) >= nodes["a"][i]).all()
+            assert (tri.max(0) <= nodes["b"][i]).all()
+    assert seen == N
+
+
+@pytest.mark.parametrize("fixture", ["bunny", "monkey", "courtyard_small"])
+def test_bvh_builder_bit_identical_to_oracle(request, oracle_lib, fixture):
+    m = request.getfixturevalue(fixture)
+    n_o, i_o, d_o = oracle_lib.build_bvh(m["positions"], m["indices_in"])
+    assert n_o.tobytes() == m["nodes"].tobytes()
+    assert np.array_equal(i_o, m["indices"]) and d_o == m["depth"]
+    for threads in (1, 3):
+        n_p, i_p, _ = pt.build_bvh(m["positions"], m["indices_in"], threads)
+        assert n_p.tobytes() == n_o.tobytes() and np.array_equal(i_p, i_o)
+    _check_bvh_invariants(m["nodes"], m["indices"], m["positions"])
+    # the same set of triangles, only reordered
+    assert sorted(map(tuple, m["indices"].tolist())) == sorted(map(tuple, m["indices_in"].tolist()))
+
+
+def test_bvh_builder_small_and_degenerate_inputs(oracle_lib):
+    pos, aux, idx = pt.scenes.cornell_box()
+    n_o, i_o, _ = oracle_lib.build_bvh(pos, idx)
+    n_p, i_p, _ = pt.build_bvh(pos, idx)
+    assert n_p.tobytes() == n_o.tobytes() and np.array_equal(i_p, i_o)
+    # one triangle: a single leaf; coincident centroids: the median fallback (BVH.cpp:269-275)
+    one_p = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [0, 1, 0, 1]], dtype=np.float32)
+    n1, _, _ = pt.build_bvh(one_p, np.array([[0, 1, 2]], dtype=np.uint32))
+    assert n1.shape[0] == 1 and n1["right"][0] == 0 and n1["next"][0] == 0
+    same = np.tile(np.array([[0, 1, 2]], dtype=np.uint32), (9, 1))
+    n_o, i_o, _ = oracle_lib.build_bvh(one_p, same)
+    n_p, i_p, _ = pt.build_bvh(one_p, same)
+    assert n_p.tobytes() == n_o.tobytes() and n_p.shape[0] == 17
+    with pytest.raises(pt.PtError):
+        pt.build_bvh(one_p, np.array([[0, 1, 7]], dtype=np.uint32))
+    with pytest.raises(pt.PtError):
+        pt.build_bvh(one_p, np.zeros((0, 3), dtype=np.uint32))
+
+
+def test_flatten_pass(bunny):
+    n2, tr, rb, ms = pt.flatten_bvh(bunny["nodes"], bunny["positions"], bunny["indices"])
+    nodes, ridx, pos = bunny["nodes"], bunny["indices"], bunny["positions"]
+    T = ridx.shape[0]
+    assert n2.shape[0] == T - 1 and tr.shape[0] == T and ms == bunny["depth"]
+    assert np.array_equal(rb[:3], nodes["a"][0]) and np.array_equal(rb[3:], nodes["b"][0])
+    interior = np.nonzero(nodes["right"] > 0)[0]
+    assert np.array_equal(n2["refIndex"], interior)
+    # boxes are the reference's, pre-digested: c = (a+b)*0.5f, h = f16(a-c), f16(b-c)
+    for side, child in (("L", interior + 1), ("R", nodes["right"][interior])):
+        a, b = nodes["a"][child], nodes["b"][child]
+        c = ((a + b) * np.float32(0.5)).astype(np.float32)
+        assert np.array_equal(n2["c" + side], c)
+        h = np.concatenate([(a - c).astype(np.float16), (b - c).astype(np.float16)], axis=1).view(np.uint16)
+        assert np.array_equal(n2["h" + side], h)
+    # triangles inline, edges as fp32 differences
+    assert np.array_equal(tr["i1"], ridx[:, 0].astype(np.int32))
+    assert np.array_equal(tr["p1"], pos[ridx[:, 0], :3])
+    assert np.array_equal(tr["e1"], pos[ridx[:, 1], :3] - pos[ridx[:, 0], :3])
+    assert np.array_equal(tr["e2"], pos[ridx[:, 2], :3] - pos[ridx[:, 0], :3])
+    leaf_nodes = np.nonzero(nodes["right"] <= 0)[0]
+    assert np.array_equal(np.sort(tr["refLeaf"]), leaf_nodes)
+    assert tr["flags"].sum() == 1 and tr["refLeaf"][tr["flags"] == 1][0] == nodes.shape[0] - 1
+    # child references resolve to the same subtrees
+    lref = n2["left"]
+    is_leaf = (lref & 0x80000000) != 0
+    assert np.array_equal(is_leaf, nodes["right"][interior + 1] <= 0)
+    with pytest.raises(pt.PtError):
+        pt.flatten_bvh(nodes[:-1], pos, ridx)
+
+
+def test_fill_constants():
+    c = pt.fill_constants(1920, 1080, 5, 100, 199, frame_index=7)
+    assert c["numRays"][0] == 5 and c["frameIndex"][0] == 7 and c["numBVHNodes"][0] == 199
+    assert tuple(c["viewportSize"][0]) == (1920.0, 1080.0) and tuple(c["viewportBase"][0]) == (0.0, 0.0)
+    v, p = c["viewMtx"][0].reshape(4, 4).T, c["projMtx"][0].reshape(4, 4).T       # column-major -> row-major
+    vi, pi = c["viewInvMtx"][0].reshape(4, 4).T, c["projInvMtx"][0].reshape(4, 4).T
+    assert np.allclose(v @ vi, np.eye(4), atol=1e-5) and np.allclose(p @ pi, np.eye(4), atol=1e-4)
+    eye = vi[:3, 3]
+    assert np.allclose(eye, (3.0, 0.5, 0.0), atol=1e-6)                            # PathTracer.cpp:109-112,734
+    assert p[1, 1] < 0                                                             # the y flip of PathTracer.cpp:737
+    assert np.isclose(-p[1, 1], 1 / np.tan(np.radians(30)), rtol=1e-6)
+    assert np.allclose(c["ambientRadiance"][0], (0.4, 0.5, 0.7))
+
+
+def test_blue_noise_table_is_the_reference_table():
+    import hashlib
+    bn = pt.load_blue_noise()
+    assert hashlib.sha256(bn.astype("<u2").tobytes()).hexdigest() == "4762b68dd49315e4c17cde4abc0f143cde425ed3a361182e71191239e94685b8"
+    assert sorted(bn.tolist()) == list(range(65536))
+
+
+def test_procedural_scenes_are_deterministic_and_clean():
+    for gen, kw in ((pt.scenes.cornell_box, {}), (pt.scenes.courtyard, dict(num_triangles=20000, seed=5))):
+        p1, a1, i1 = gen(**kw)
+        p2, a2, i2 = gen(**kw)
+        assert np.array_equal(p1, p2) and np.array_equal(i1, i2) and a1.tobytes() == a2.tobytes()
+        tri = p1[i1][:, :, :3]
+        area = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+        assert (area > 0).all()
+        assert np.allclose(np.linalg.norm(a1["normal"], axis=1), 1, atol=1e-5)
+    p, a, i = pt.scenes.courtyard(50000)
+    assert abs(i.shape[0] - 50000) < 1500

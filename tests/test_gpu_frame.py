@@ -1,0 +1,237 @@
+"""Parity of the wavefront stages (launch, closest-hit, shade + NEE, shadow, compaction, resolve +
+accumulate) with the CPU oracle, through the C ABI dispatch sites.
+
+Bar: every byte of the ray stack, the RGBA16F current image and the RGBA32F accumulation equal the
+oracle's for the reference-order traversal.  The only arithmetic not guaranteed identical is the
+fp32 pow/sin/cos under the fp16 shading (libm on the CPU, ocml on the GPU, both rounded to fp16);
+a differing pixel would show up here as an inequality and is bounded at 1e-3 of pixels and an RMSE
+of 1e-3 x mean radiance."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle
+import pathtracer_amd as pt
+from pathtracer_amd import core
+
+pytestmark = pytest.mark.gpu
+
+BUNNY_CAM = dict(orbit_angle=-np.pi / 2, orbit_height=0.75, focus_center=(0.0, 0.75, 0.0))
+
+
+def _setup(ctx, model, W, H, NR):
+    lights, bn = pt.default_lights(), pt.load_blue_noise()
+    helpers.upload(ctx, model, lights, bn)
+    ctx.resize(W, H, NR)
+    for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0)):
+        ctx.set_option(o, v)
+    return helpers.oracle_scene(model, lights, bn), oracle.Frame(W, H, NR)
+
+
+def _consts(model, W, H, NR, frame, cam):
+    return pt.fill_constants(W, H, NR, model["indices"].shape[0], model["nodes"].shape[0], frame_index=frame, **cam)
+
+
+def _compare(ctx, fr, strict=True):
+    slots, _ = ctx.readback_raystack()
+    acc, cur = ctx.readback_accumulation(), ctx.readback_current()
+    if strict:
+        assert np.array_equal(slots.view(np.uint8), fr.stack.view(np.uint8)), "ray stack differs"
+        assert np.array_equal(cur, fr.current)
+        assert np.array_equal(acc, fr.accumulation)
+    else:
+        bad = (np.abs(acc - fr.accumulation).max(axis=2) > 0).mean()
+        rmse = np.sqrt(((acc - fr.accumulation)[..., :3] ** 2).mean())
+        assert bad <= 1e-3 and rmse <= 1e-3 * max(fr.accumulation[..., :3].mean(), 1e-6)
+
+
+@pytest.mark.parametrize("name,cam", [("bunny", BUNNY_CAM), ("monkey", {})])
+@pytest.mark.parametrize("trav", [core.TRAVERSAL_FLAT, core.TRAVERSAL_REFERENCE_LAYOUT])
+def test_frames_match_oracle(gpu_ctx, oracle_lib, request, name, cam, trav):
+    model = request.getfixturevalue(name)
+    W, H, NR = 256, 144, 4
+    osc, fr = _setup(gpu_ctx, model, W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
+    for frame in (1, 2, 3):
+        c = _consts(model, W, H, NR, frame, cam)
+        gpu_ctx.set_constants(c)
+        rc = gpu_ctx.render_sample(frame, want_ray_counts=True)
+        before = fr.ray_counts().copy()
+        oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        after = fr.ray_counts()
+        _compare(gpu_ctx, fr)
+        assert int(rc[0::2][:NR].sum()) == int(after[0] - before[0])       # closest-hit rays
+        assert int(rc[1::2][:NR].sum()) == int(after[1] - before[1])       # shadow rays
+        assert int(rc[0]) == W * H
+    assert (gpu_ctx.readback_accumulation()[..., 3] == 3).all()
+
+
+def test_dispatch_sites_one_by_one(gpu_ctx, oracle_lib, monkey):
+    """launch / trace / compact / resolve called individually, with and without compaction, equal render_sample."""
+    W, H, NR = 128, 72, 3
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    c = _consts(monkey, W, H, NR, 1, {})
+    gpu_ctx.set_constants(c)
+    gpu_ctx.launch()
+    slots, jobs = gpu_ctx.readback_raystack()
+    oracle.launch(osc, fr, c)
+    assert np.array_equal(slots.view(np.uint8), fr.stack.view(np.uint8)) and np.array_equal(jobs, fr.jobs)
+    for d in range(NR):
+        gpu_ctx.trace(d)
+        oracle.trace(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        slots, jobs = gpu_ctx.readback_raystack()
+        assert np.array_equal(slots.view(np.uint8), fr.stack.view(np.uint8)), f"depth {d}"
+        live_g = np.sort(jobs[jobs != 0xFFFFFFFF]); live_o = np.sort(fr.jobs[fr.jobs != 0xFFFFFFFF])
+        assert np.array_equal(live_g, live_o)
+        if d == 0:      # compaction keeps exactly the live jobs, densely packed (raysort.comp:23-55 keeps them per segment)
+            gpu_ctx.compact()
+            oracle.raysort(fr, c)
+            _, jobs = gpu_ctx.readback_raystack()
+            assert np.array_equal(np.sort(jobs[:len(live_o)]), live_o)
+    gpu_ctx.resolve_accumulate()
+    oracle.composite(fr, c)
+    _compare(gpu_ctx, fr)
+
+
+def test_speculative_depth0_matches_subgroup64(gpu_ctx, oracle_lib, monkey):
+    """The SPECULATIVE build (subgroup vote) at depth 0 with 64-lane subgroups on 8x8 tiles."""
+    W, H, NR = 128, 72, 3
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    for frame in (1, 2):
+        c = _consts(monkey, W, H, NR, frame, {})
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_sample(frame, speculative_depth0=True)
+        oracle.render_frame(osc, fr, c, subgroup0=64, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        _compare(gpu_ctx, fr)
+
+
+def test_stale_slot_and_reseed_options(gpu_ctx, oracle_lib, monkey):
+    W, H, NR = 96, 64, 4
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_STALE_SLOTS, 1)
+    gpu_ctx.set_option(core.OPT_RESEED, 1)
+    for frame in (1, 2, 3):
+        c = _consts(monkey, W, H, NR, frame, {})
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_sample(frame)
+        oracle.render_frame(osc, fr, c, mode=oracle.MODE_RESEED_EVERY_FRAME | oracle.MODE_KILL_ON_MISS)
+        _compare(gpu_ctx, fr)
+    gpu_ctx.set_option(core.OPT_STALE_SLOTS, 0)
+    gpu_ctx.set_option(core.OPT_RESEED, 0)
+
+
+def test_eight_slots_and_clear(gpu_ctx, oracle_lib, bunny):
+    """numRays = 8 (beyond the reference's cap of 5, PathTracer.cpp:96,448) and the accumulation clear."""
+    W, H, NR = 160, 96, 8
+    osc, fr = _setup(gpu_ctx, bunny, W, H, NR)
+    for frame in (1, 2):
+        c = _consts(bunny, W, H, NR, frame, BUNNY_CAM)
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_sample(frame)
+        oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+    _compare(gpu_ctx, fr)
+    gpu_ctx.clear_accumulation()
+    fr.clear_accumulation()
+    c = _consts(bunny, W, H, NR, 3, BUNNY_CAM)
+    gpu_ctx.set_constants(c)
+    gpu_ctx.render_sample(3)
+    oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+    _compare(gpu_ctx, fr)          # launch reseeds after the clear (launch.comp:49-50)
+
+
+def test_full_size_properties_1080p(gpu_ctx, bunny):
+    """BASELINE config: CBbunny 1080p, primary + one bounce (numRays = 2).  Too large for the scalar oracle in a
+    test; checked through properties: sample counts, finiteness, ray-count bookkeeping, determinism."""
+    W, H, NR = 1920, 1080, 2
+    lights, bn = pt.default_lights(), pt.load_blue_noise()
+    helpers.upload(gpu_ctx, bunny, lights, bn)
+    gpu_ctx.resize(W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+    c = _consts(bunny, W, H, NR, 1, BUNNY_CAM)
+    gpu_ctx.set_constants(c)
+    images = []
+    for rep in range(2):
+        gpu_ctx.clear_accumulation()
+        tot = np.zeros(2 * NR, dtype=np.uint64)
+        for frame in (1, 2, 3, 4):
+            rc = gpu_ctx.render_sample(frame, want_ray_counts=True)
+            assert rc[0] == W * H and rc[2] <= rc[1] and rc[3] <= rc[2]      # closest[d+1] <= shadow[d] = hits[d]
+            tot += rc[:2 * NR]
+        acc = gpu_ctx.readback_accumulation()
+        assert (acc[..., 3] == 4).all() and np.isfinite(acc).all() and (acc[..., :3] >= 0).all()
+        assert acc[..., :3].mean() > 1e-3
+        images.append(acc)
+    assert np.array_equal(images[0], images[1])
+
+
+def test_ordered_traversal_image_rmse(gpu_ctx, oracle_lib, monkey):
+    """Near-child-first traversal changes a small fraction of hits (fp16 box-test edge cases); the image stays
+    within an RMSE of 2 % of the mean radiance after 4 samples at equal seed."""
+    W, H, NR = 128, 72, 4
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+    gpu_ctx.set_option(core.OPT_RESEED, 1)
+    for frame in (1, 2, 3, 4):
+        c = _consts(monkey, W, H, NR, frame, {})
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_sample(frame)
+        oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_RESEED_EVERY_FRAME)
+    acc = gpu_ctx.readback_accumulation()
+    rmse = np.sqrt(((acc - fr.accumulation)[..., :3] ** 2).mean()) / 4
+    mean = fr.accumulation[..., :3].mean() / 4
+    print(f"ordered traversal: image rmse {rmse:.3e} vs mean radiance {mean:.3e}")
+    assert rmse <= 0.02 * mean
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+    gpu_ctx.set_option(core.OPT_RESEED, 0)
+
+
+def test_error_behaviour(oracle_lib, bunny):
+    ctx = pt.PathTracer(0)
+    try:
+        with pytest.raises(pt.PtError):
+            ctx.launch()                                   # nothing uploaded
+        with pytest.raises(pt.PtError):
+            ctx.trace_rays(np.zeros(4, dtype=pt.RAY_DT))
+        bad = bunny["nodes"].copy(); bad["right"][0] = 10 ** 9
+        with pytest.raises(pt.PtError):
+            ctx.upload_scene(bunny["positions"], bunny["aux"], bunny["indices"], bad)
+        helpers.upload(ctx, bunny, pt.default_lights(), pt.load_blue_noise())
+        with pytest.raises(pt.PtError):
+            ctx.launch()                                   # no resize yet
+        ctx.resize(64, 64, 2)
+        with pytest.raises(pt.PtError):
+            ctx.set_constants(pt.fill_constants(64, 64, 5, bunny["indices"].shape[0], bunny["nodes"].shape[0]))   # numRays > slots
+        with pytest.raises(pt.PtError):
+            ctx.set_constants(pt.fill_constants(32, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))   # wrong viewport
+        with pytest.raises(pt.PtError):
+            ctx.set_option(core.OPT_TRAVERSAL, 9)
+        ctx.set_constants(pt.fill_constants(64, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))
+        ctx.render_sample(1)
+        assert (ctx.readback_accumulation()[..., 3] == 1).all()
+    finally:
+        ctx.close()
+
+
+def test_allreduce_single_rank(gpu_ctx, monkey):
+    """RCCL path with one rank: the sum over one rank leaves the buffer as it is, through both routes."""
+    from pathtracer_amd import distributed as ptd
+    W, H, NR = 64, 48, 2
+    helpers.upload(gpu_ctx, monkey, pt.default_lights(), pt.load_blue_noise())
+    gpu_ctx.resize(W, H, NR)
+    gpu_ctx.set_constants(_consts(monkey, W, H, NR, 1, {}))
+    gpu_ctx.render_sample(1)
+    before = gpu_ctx.readback_accumulation()
+    gpu_ctx.comm_init(0, 1, core.comm_unique_id())
+    gpu_ctx.allreduce_accumulation()
+    gpu_ctx.synchronize()
+    assert np.array_equal(gpu_ctx.readback_accumulation(), before)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1)
+    try:
+        t = ptd.allreduce_accumulation_torch(gpu_ctx)
+        assert t.data_ptr() == gpu_ctx.accumulation_device_ptr()
+        assert np.array_equal(gpu_ctx.readback_accumulation(), before)
+    finally:
+        dist.destroy_process_group()

@@ -68,14 +68,33 @@ def test_other_scenes_exact(gpu_ctx, oracle_lib, request, model_name, traversal)
 
 @pytest.mark.parametrize("model_name", ["bunny", "monkey", "courtyard_small"])
 def test_ordered_traversal_within_bar(gpu_ctx, oracle_lib, request, model_name):
+    """Near-child-first order: the reference's fp16 box test is not conservative, so which of two hits that lie
+    within its error of each other survives depends on visit order.  Bar: triangle ids agree on >= 99.99 % of rays,
+    every disagreement is a near-tie (|dt| below the fp16 box-test resolution, 2^-9 of the scene extent), and t
+    agrees to 1e-5 relative on all other rays.  The any-hit verdict does not depend on order at all (max_t is
+    constant until the first accepted hit ends the walk)."""
     model = request.getfixturevalue(model_name)
     helpers.upload(gpu_ctx, model)
     osc = helpers.oracle_scene(model)
     a, b = model["nodes"][0]["a"], model["nodes"][0]["b"]
-    rays = np.concatenate([helpers.random_rays(a, b, 200_000, seed=21), helpers.camera_rays(640, 360)])
-    frac = _check(gpu_ctx, model, osc, rays, False, core.TRAVERSAL_FLAT_ORDERED, exact=False)
+    rays = np.concatenate([helpers.random_rays(a, b, 400_000, seed=21), helpers.camera_rays(640, 360)])
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+    hits = gpu_ctx.trace_rays(rays)
+    ref = osc.trace(rays)
+    assert np.array_equal(hits["i1"] >= 0, ref["i1"] >= 0)
+    same = (hits["i1"] == ref["i1"]) & (hits["i2"] == ref["i2"]) & (hits["i3"] == ref["i3"])
+    frac = float((~same).mean())
     print(f"{model_name}: near-first order differs from the reference order on {frac:.2e} of rays")
-    _check(gpu_ctx, model, osc, rays, True, core.TRAVERSAL_FLAT_ORDERED, exact=False)
+    assert frac <= 1e-4
+    extent = float((b - a).max())
+    assert np.abs(hits["t"][~same] - ref["t"][~same]).max(initial=0.0) <= extent / 512
+    hit = same & (ref["i1"] >= 0)
+    rel = np.abs(hits["t"][hit] - ref["t"][hit]) / np.maximum(np.abs(ref["t"][hit]), 1e-30)
+    assert rel.max() <= 1e-5
+    any_g = gpu_ctx.trace_rays(rays, any_hit=True)
+    any_o = osc.trace(rays, any_hit=True)
+    assert np.array_equal(any_g["i1"] >= 0, any_o["i1"] >= 0)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
 
 
 def test_stats_match_oracle_counts(gpu_ctx, oracle_lib, bunny):
