@@ -129,6 +129,18 @@ def main():
     mrays = total_rays / elapsed / 1e6
     achieved = bytes_per_ray * n / (kernel_ms * 1e-3) / 1e9
 
+    # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (bench.py cannot
+    # collect counters on itself); profiles/traffic.json holds the latest, keyed by workload
+    traffic = None
+    trav = args.traversal if args.traversal >= 0 else 2
+    try:
+        for rec in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["records"]:
+            k = rec["key"]
+            if k["triangles"] == int(ridx.shape[0]) and k["rays_per_gpu"] == n and k["traversal"] == trav:
+                traffic = rec["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     result = {
         "metric": "incoherent closest-hit Mrays/s",
         "value": round(mrays, 2),
@@ -149,7 +161,7 @@ def main():
             "triangles": int(ridx.shape[0]),
             "bvh_nodes": int(nodes.shape[0]),
             "traversal": {0: "reference 32 B nodes, stackless", 1: "flattened 64 B records, reference visit order",
-                          2: "flattened 64 B records, near child first"}[args.traversal if args.traversal >= 0 else 1],
+                          2: "flattened 64 B records, near child first"}[trav],
             "hit_rate": round(hit_rate, 4),
             "box_tests_per_ray": round(box_per_ray, 2),
             "triangle_tests_per_ray": round(tri_per_ray, 3),
@@ -161,7 +173,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": traffic,
             "kernel": "k_trace_flat<MODE_RAYS> (closest hit)",
             "kernel_ms": round(kernel_ms, 3),
             "bytes_per_ray": round(bytes_per_ray, 1),

@@ -63,7 +63,7 @@ struct PtContext {
     /* scene (bindings 1,2,3,4,7,8) */
     float4* dPositions = nullptr; PtVertexAux* dAux = nullptr; uint32_t* dIndices = nullptr; PtBVHNode* dNodes = nullptr;
     PtLight* dLights = nullptr; uint16_t* dBlueNoise = nullptr;
-    uint4* dNodes2 = nullptr; uint4* dTris = nullptr; uint2* dOverflow = nullptr;
+    uint4* dRecords = nullptr; uint2* dOverflow = nullptr; uint32_t leafBase = 0, recordBytes = 0;
     uint32_t V = 0, T = 0, N = 0, L = 0, maxStack = 0, overflowEntries = 0;
     uint64_t overflowLanes = 0;
     float rootBox[6] = {0}; float rootC[3] = {0}; uint16_t rootH[6] = {0};
@@ -75,7 +75,7 @@ struct PtContext {
     uint32_t* dCtr = nullptr; unsigned long long* dStats = nullptr; unsigned long long* dRayCounts = nullptr;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 1, optStale = 0, optReseed = 0, optBlocksPerCU = 6, optRefillMin = 24;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 6, optRefillMin = 36;
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
 
@@ -95,7 +95,7 @@ template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; }
 void free_scene(PtContext* c)
 {
     dfree(c->dPositions); dfree(c->dAux); dfree(c->dIndices); dfree(c->dNodes); dfree(c->dLights); dfree(c->dBlueNoise);
-    dfree(c->dNodes2); dfree(c->dTris); dfree(c->dOverflow);
+    dfree(c->dRecords); dfree(c->dOverflow);
     c->V = c->T = c->N = c->L = 0;
 }
 void free_frame(PtContext* c)
@@ -121,7 +121,7 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
 {
     memset(&a, 0, sizeof(a));
     a.nodes = c->dNodes; a.numNodes = c->N; a.indices = c->dIndices; a.positions = c->dPositions;
-    a.nodes2 = c->dNodes2; a.tris = c->dTris;
+    a.records = c->dRecords; a.recordBytes = c->recordBytes; a.leafBase = c->leafBase; a.tris = c->dRecords + c->leafBase / 16;
     for (int k = 0; k < 3; k++) a.rootC[k] = c->rootC[k];
     for (int k = 0; k < 6; k++) a.rootH[k] = c->rootH[k];
     a.rootRef = (c->T == 1) ? PT_LEAF_BIT : 0u;
@@ -285,13 +285,16 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
     HIPCHK(hipMalloc((void**)&ctx->dPositions, (size_t)V * 16));
     HIPCHK(hipMalloc((void**)&ctx->dIndices, (size_t)T * 12));
     HIPCHK(hipMalloc((void**)&ctx->dNodes, (size_t)N * sizeof(PtBVHNode)));
-    HIPCHK(hipMalloc((void**)&ctx->dNodes2, n2.size() * sizeof(PtNode2)));
-    HIPCHK(hipMalloc((void**)&ctx->dTris, (size_t)T * sizeof(PtTri)));
+    /* interior records and leaf records share one buffer so that one buffer descriptor serves every fetch */
+    const size_t interiorBytes = (size_t)(T - 1) * sizeof(PtNode2), recBytes = interiorBytes + (size_t)T * sizeof(PtTri);
+    if (recBytes >= 0xFFFFFFFFull) return ctx->fail(-1, "pt_scene_upload: more than 2^32 bytes of traversal records (about 33 M triangles)");
+    HIPCHK(hipMalloc((void**)&ctx->dRecords, recBytes));
+    ctx->leafBase = (uint32_t)interiorBytes; ctx->recordBytes = (uint32_t)recBytes;
     HIPCHK(hipMemcpy(ctx->dPositions, positions, (size_t)V * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->dIndices, indices, (size_t)T * 12, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->dNodes, nodes, (size_t)N * sizeof(PtBVHNode), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->dNodes2, n2.data(), n2.size() * sizeof(PtNode2), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ctx->dTris, tr.data(), (size_t)T * sizeof(PtTri), hipMemcpyHostToDevice));
+    if (T > 1) HIPCHK(hipMemcpy(ctx->dRecords, n2.data(), interiorBytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((char*)ctx->dRecords + interiorBytes, tr.data(), (size_t)T * sizeof(PtTri), hipMemcpyHostToDevice));
     if (aux) {
         HIPCHK(hipMalloc((void**)&ctx->dAux, (size_t)V * 16));
         HIPCHK(hipMemcpy(ctx->dAux, aux, (size_t)V * 16, hipMemcpyHostToDevice));

@@ -27,7 +27,10 @@
 
 #pragma clang fp contract(off)
 
-#define PT_STACK_LDS 16          /* per-lane stack entries held in LDS; deeper entries spill to global memory */
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 12          /* per-lane stack entries held in LDS; deeper entries spill to global memory */
+#endif
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PT_WAVES_PER_BLOCK 4
 #define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
 
@@ -56,9 +59,11 @@ struct TraceArgs {
     const PtBVHNode* nodes;  uint32_t numNodes;
     const uint32_t*  indices;
     const float4*    positions;
-    /* flattened layout */
-    const uint4*     nodes2;
-    const uint4*     tris;
+    /* flattened layout: one buffer, interior records first, then leaf records */
+    const uint4*     records;
+    uint32_t         recordBytes;    /* size of that buffer */
+    uint32_t         leafBase;       /* byte offset of the first leaf record */
+    const uint4*     tris;           /* = records + leafBase/16 */
     float            rootC[3]; uint16_t rootH[6]; uint32_t rootRef;
     uint2*           overflow;       /* [entry][global lane] spill area of the LDS stacks */
     uint32_t         overflowEntries;
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     float alpha = 0, beta = 0, gamma = 0;
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
 
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
     const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
 
@@ -303,9 +309,15 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         if (!active) continue;
 
         /* one step: fetch the 64 B record `cur` names, then two box tests or one triangle test */
+        /* the whole record comes in with four 16 B buffer loads issued back to back; the empty asm keeps the
+           compiler from splitting them into narrower per-branch loads */
         const bool leaf = (cur & PT_LEAF_BIT) != 0;
-        const uint4* rec = (leaf ? a.tris : a.nodes2) + (size_t)(cur & ~PT_LEAF_BIT) * 4;
-        uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+        const uint32_t off = ((cur & ~PT_LEAF_BIT) << 6) + (leaf ? a.leafBase : 0u);
+        u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
+        u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
+        u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
         if (COUNT) nRec++;
         bool needPop = true, done = false;
 
