@@ -102,10 +102,9 @@ typedef struct PtHit {
  * Child reference: bit 31 set = leaf, low 31 bits = index into the triangle records;
  * clear = index into the PtNode2 array. */
 typedef struct PtNode2 {
-    float    cL[3];
-    uint16_t hL[6];              /* f16(aL-cL) xyz, f16(bL-cL) xyz */
-    float    cR[3];
-    uint16_t hR[6];
+    float    cL[3];              /* centre of the left child's box */
+    float    cR[3];              /* centre of the right child's box */
+    uint16_t h[6][2];            /* f16(a-c).xyz then f16(b-c).xyz, each stored as the pair (left child, right child) */
     uint32_t left, right;
     uint32_t refIndex;           /* index of this interior node in the reference array */
     uint32_t _pad;
@@ -176,7 +175,7 @@ PT_API void*       pt_stream(PtContext* ctx);          /* the context's hipStrea
 /* Options (no reference counterpart; they select among documented behaviours). */
 enum {
     PT_OPT_TRAVERSAL      = 1,   /* 0 = reference 32 B nodes, stackless walk; 1 = PtNode2, reference visit
-                                    order (default, results identical to 0); 2 = PtNode2, near child first */
+                                    order (results identical to 0); 2 = PtNode2, near child first (default) */
     PT_OPT_STALE_SLOTS    = 2,   /* 0 = zero prob of the next slot when a path ends (default); 1 = leave
                                     deeper slots as they are, as composite.frag:35-49 finds them */
     PT_OPT_RESEED         = 3,   /* 0 = seed the LCG only after a clear (launch.comp:49-50, default);

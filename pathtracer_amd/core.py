@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 NODE_DT = np.dtype([("a", "<f4", 3), ("next", "<i4"), ("b", "<f4", 3), ("right", "<i4")])
-NODE2_DT = np.dtype([("cL", "<f4", 3), ("hL", "<u2", 6), ("cR", "<f4", 3), ("hR", "<u2", 6), ("left", "<u4"), ("right", "<u4"),
+NODE2_DT = np.dtype([("cL", "<f4", 3), ("cR", "<f4", 3), ("h", "<u2", (6, 2)), ("left", "<u4"), ("right", "<u4"),
                      ("refIndex", "<u4"), ("_pad", "<u4")])
 TRI_DT = np.dtype([("p1", "<f4", 3), ("i1", "<i4"), ("e1", "<f4", 3), ("i2", "<i4"), ("e2", "<f4", 3), ("i3", "<i4"),
                    ("refLeaf", "<u4"), ("flags", "<u4"), ("_pad", "<u4", 2)])

@@ -75,7 +75,7 @@ struct PtContext {
     uint32_t* dCtr = nullptr; unsigned long long* dStats = nullptr; unsigned long long* dRayCounts = nullptr;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 6, optRefillMin = 36;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36;
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
 

@@ -64,8 +64,10 @@ extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
         if (n.right > 0) {
             PtNode2& o = nodes2[rank[i]];
             memset(&o, 0, sizeof(o));
-            digest_box(nodes[i + 1], o.cL, o.hL);
-            digest_box(nodes[n.right], o.cR, o.hR);
+            uint16_t hl[6], hr[6];
+            digest_box(nodes[i + 1], o.cL, hl);
+            digest_box(nodes[n.right], o.cR, hr);
+            for (int k = 0; k < 6; k++) { o.h[k][0] = hl[k]; o.h[k][1] = hr[k]; }
             o.left = child_ref(i + 1);
             o.right = child_ref((uint32_t)n.right);
             o.refIndex = i;

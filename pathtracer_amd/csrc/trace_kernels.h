@@ -265,6 +265,34 @@ __global__ __launch_bounds__(64) void k_trace_ref_speculative(TraceArgs a, uint3
 
 /* ---- flattened-layout walk -------------------------------------------------------------------- */
 
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ h16x2 as_h2(uint32_t u) { return __builtin_bit_cast(h16x2, u); }
+
+/* Both children's boxes of one interior record at once: the fields are stored as (left, right) half pairs, so every
+ * fp16 operation of intersections.glsl:11-27 runs as one packed instruction on both boxes.  Element-wise the
+ * arithmetic is the scalar box_static's, operation for operation. */
+__device__ __forceinline__ void box_pair(const RayRegs& r, h16x2 rx, h16x2 ry, h16x2 rz, u32x4 q0, u32x4 q1, u32x4 q2,
+                                         bool& sL, bool& sR, float& tminL, float& tminR)
+{
+    const float cLx = __uint_as_float(q0.x), cLy = __uint_as_float(q0.y), cLz = __uint_as_float(q0.z);
+    const float cRx = __uint_as_float(q0.w), cRy = __uint_as_float(q1.x), cRz = __uint_as_float(q1.y);
+    f32x2 dx = { r.o.x - cLx, r.o.x - cRx }, dy = { r.o.y - cLy, r.o.y - cRy }, dz = { r.o.z - cLz, r.o.z - cRz };
+    h16x2 ox = __builtin_convertvector(dx, h16x2), oy = __builtin_convertvector(dy, h16x2), oz = __builtin_convertvector(dz, h16x2);
+    h16x2 t0 = (as_h2(q1.z) - ox) * rx, t1 = (as_h2(q2.y) - ox) * rx;
+    h16x2 tmin = __builtin_elementwise_min(t0, t1), tmax = __builtin_elementwise_max(t0, t1);
+    t0 = (as_h2(q1.w) - oy) * ry; t1 = (as_h2(q2.z) - oy) * ry;
+    tmin = __builtin_elementwise_max(tmin, __builtin_elementwise_min(t0, t1));
+    tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
+    t0 = (as_h2(q2.x) - oz) * rz; t1 = (as_h2(q2.w) - oz) * rz;
+    tmin = __builtin_elementwise_max(tmin, __builtin_elementwise_min(t0, t1));
+    tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
+    const float fminL = (float)tmin.x, fminR = (float)tmin.y, fmaxL = (float)tmax.x, fmaxR = (float)tmax.y;
+    sL = (fmaxL > 0.0f || fminL > 0.0f) && fmaxL >= fminL && r.min_t < fmaxL;
+    sR = (fmaxR > 0.0f || fminR > 0.0f) && fmaxR >= fminR && r.min_t < fmaxR;
+    tminL = fminL; tminR = fminR;
+}
+
 template <int MODE, bool ANYHIT, bool ORDERED, bool COUNT>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
 {
@@ -274,19 +302,25 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
     const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
 
     bool active = false, exhausted = false;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
+    h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;       /* rcpD duplicated into both halves */
     uint32_t cur = 0; int sp = 0;
-    bool hit = false, ranOff = false; uint32_t hitTri = 0;
+    bool hit = false, ranOff = false;
+    int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1; uint32_t hitLeaf = 0;     /* ids come with the leaf record: no second fetch when the ray ends */
     float alpha = 0, beta = 0, gamma = 0;
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+#ifdef PT_EXPERIMENT_TIMING
+    unsigned long long tFetch = 0, tIter = 0, nIter = 0, nLaneSteps = 0, t0 = __builtin_amdgcn_s_memtime();
+#endif
 
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
     const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
 
     for (;;) {
+        /* ---- refill idle lanes from the global ray pool ---- */
         uint64_t idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
         if (nIdle == 64 && exhausted) break;
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 if (load_ray<MODE>(a, id, r, exclude, tag)) {
                     if (COUNT) { nRay++; nBox++; }
                     hit = false; ranOff = false; sp = 0;
+                    rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
                     float ftmin;
                     bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
                     if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
@@ -308,16 +343,23 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         }
         if (!active) continue;
 
-        /* one step: fetch the 64 B record `cur` names, then two box tests or one triangle test */
-        /* the whole record comes in with four 16 B buffer loads issued back to back; the empty asm keeps the
-           compiler from splitting them into narrower per-branch loads */
+        /* ---- one step: fetch the 64 B record `cur` names with four 16 B buffer loads issued back to back (the
+                empty asm keeps the compiler from splitting them into narrower per-branch loads, which cost twice
+                the L2 requests), then run two box tests or one triangle test ---- */
         const bool leaf = (cur & PT_LEAF_BIT) != 0;
         const uint32_t off = ((cur & ~PT_LEAF_BIT) << 6) + (leaf ? a.leafBase : 0u);
+#ifdef PT_EXPERIMENT_TIMING
+        unsigned long long ta = __builtin_amdgcn_s_memtime();
+#endif
         u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
         u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
         u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+#ifdef PT_EXPERIMENT_TIMING
+        unsigned long long tb_ = __builtin_amdgcn_s_memtime();
+        { unsigned long long am = __ballot(true); if (lane == __ffsll(am) - 1) { tFetch += tb_ - ta; nIter++; nLaneSteps += __popcll(am); } }
+#endif
         if (COUNT) nRec++;
         bool needPop = true, done = false;
 
@@ -331,53 +373,56 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
                 if (tri_test(r, p1, e1, e2, t, al, be, ga)) {
                     r.max_t = t; alpha = al; beta = be; gamma = ga;
-                    hit = true; hitTri = cur & ~PT_LEAF_BIT;
+                    hit = true;
+                    if (MODE != MODE_SHADOW) { hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w; }
+                    if (MODE == MODE_JOBS) hitLeaf = q3.x;
                     if (ANYHIT) { done = true; needPop = false; }
                 }
             }
         } else {
             if (COUNT) nBox += 2;
-            float tminL, tminR;
-            bool sL = box_static(r, __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z),
-                                 lo16(q0.w), hi16(q0.w), lo16(q1.x), hi16(q1.x), lo16(q1.y), hi16(q1.y), tminL);
-            bool sR = box_static(r, __uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x),
-                                 lo16(q2.y), hi16(q2.y), lo16(q2.z), hi16(q2.z), lo16(q2.w), hi16(q2.w), tminR);
-            bool pL = sL && r.max_t > tminL, pR = sR && r.max_t > tminR;
+            bool sL, sR; float tminL, tminR;
+            box_pair(r, rx, ry, rz, q0, q1, q2, sL, sR, tminL, tminR);
+            const bool pL = sL && r.max_t > tminL, pR = sR && r.max_t > tminR;
             uint32_t first = q3.x, second = q3.y; float tminSecond = tminR;
-            bool pFirst = pL, pSecond = pR;
             if (ORDERED && pL && pR && tminR < tminL) { first = q3.y; second = q3.x; tminSecond = tminL; }
-            if (pSecond && pFirst) {
-                /* push the sibling with its tmin; `max_t > tmin` is re-evaluated at pop time */
-                uint16_t tb = hbits((h16)tminSecond);                       /* exact: tmin came from an fp16 */
+            if (pL && pR) {
+                /* the sibling waits with its tmin; `max_t > tmin` is re-evaluated when it is popped */
+                const uint16_t tb = hbits((h16)tminSecond);                 /* exact: tmin came from an fp16 */
                 if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = second; sTmin[wave][sp][lane] = tb; }
                 else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, tb);
                 sp++;
                 cur = first; needPop = false;
-            } else if (pFirst) { cur = first; needPop = false; }
-            else if (pSecond) { cur = second; needPop = false; }
+            } else if (pL) { cur = q3.x; needPop = false; }
+            else if (pR) { cur = q3.y; needPop = false; }
         }
 
+        /* pending siblings come off the stack until one still passes `max_t > tmin` */
         while (needPop) {
             if (sp == 0) { done = true; break; }
             sp--;
-            uint32_t ref; uint16_t tb;
-            if (sp < PT_STACK_LDS) { ref = sRef[wave][sp][lane]; tb = sTmin[wave][sp][lane]; }
-            else { uint2 e = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = e.x; tb = (uint16_t)e.y; }
+            /* the LDS read is unconditional (clamped index) so that it stays a plain ds_read: merged with the rare
+               overflow load it would become a flat load, which goes through the vector-memory path */
+            const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
+            uint32_t ref = sRef[wave][e][lane]; uint16_t tb = sTmin[wave][e][lane];
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; tb = (uint16_t)o.y; }
             if (r.max_t > (float)hfrombits(tb)) { cur = ref; needPop = false; }
         }
 
         if (done) {
-            int32_t i1 = -1, i2 = -1, i3 = -1; uint32_t orig = 0;
-            if (hit && MODE != MODE_SHADOW) {
-                const uint32_t* tr = (const uint32_t*)(a.tris + (size_t)hitTri * 4);
-                i1 = (int32_t)tr[3]; i2 = (int32_t)tr[7]; i3 = (int32_t)tr[11];
-                if (MODE == MODE_JOBS && ranOff) orig = tr[12];
-            }
-            store_result<MODE>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, orig);
+            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, (MODE == MODE_JOBS && ranOff && hit) ? hitLeaf : 0u);
             active = false;
         }
     }
+#ifdef PT_EXPERIMENT_TIMING
+    /* diagnostic build only: per-wave cycle sums go to the stats words, which nothing else reads in this build */
+    tIter = __builtin_amdgcn_s_memtime() - t0;
+    atomicAdd(a.stats + 0, tFetch); atomicAdd(a.stats + 2, nIter); atomicAdd(a.stats + 3, nLaneSteps);
+    if (lane == 0) atomicAdd(a.stats + 1, tIter);
+    return;
+#endif
     if (COUNT) {
         atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
     }
 }
+

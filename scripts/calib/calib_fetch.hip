@@ -13,6 +13,19 @@ __global__ __launch_bounds__(256) void k_gather(const void* buf, unsigned long l
     unsigned acc = 0;
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         unsigned idx;
+        if (pattern == 3) {
+            // quad-cooperative: in round k the four lanes of a quad read the four 16 B pieces of ONE random record
+            const unsigned quadBase = i & ~3u, piece = (i & 3u) * 16u;
+            for (int k = 0; k < 4; k++) {
+                unsigned id2 = ((quadBase + k) * 2654435761u) & (n - 1);
+                const char* base2 = (const char*)buf + ((id2 >> 25) ? (1ull << 31) : 0ull);
+                __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc((void*)base2, 0, 0x7FFFFFFF, 0x00020000);
+                u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(r2, ((id2 & ((1u << 25) - 1)) << 6) + piece, 0, 0);
+                asm volatile("" : "+v"(q));
+                acc += q.x ^ q.w;
+            }
+            continue;
+        }
         if (pattern == 0) idx = i;
         else if (pattern == 1) idx = (i * 2654435761u) & (n - 1);                 // odd multiplier: a bijection on 2^logn
         else idx = ((((i >> 1) * 2654435761u) & ((n >> 1) - 1)) << 1) | (i & 1);  // random 128 B line, both halves by a lane pair
@@ -39,7 +52,8 @@ int main(int argc, char** argv)
     hipMemset(buf, 1, bytes);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; rep++) {
+    int reps = argc > 3 ? atoi(argv[3]) : 3;
+    for (int rep = 0; rep < reps; rep++) {
         hipEventRecord(e0);
         hipLaunchKernelGGL(k_gather, dim3(256 * 8), dim3(256), 0, 0, buf, bytes, logn, pattern, out);
         hipEventRecord(e1);

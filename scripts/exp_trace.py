@@ -48,6 +48,7 @@ for mode in [int(m) for m in args.modes.split(",")]:
     print(f"mode {mode}: box/ray {st[0]/n:.1f} tri/ray {st[1]/n:.2f} rec/ray {st[2]/n:.1f} hit rate {(hits['i1']>=0).mean():.3f} diff vs first mode {diff:.2e}", flush=True)
     for blocks in [int(b) for b in args.blocks.split(",")]:
         for refill in [int(r) for r in args.refill.split(",")]:
+          if True:
             ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
             ctx.set_option(core.OPT_REFILL_MIN, refill)
             ms = []

@@ -149,12 +149,12 @@ def test_flatten_pass(bunny):
     interior = np.nonzero(nodes["right"] > 0)[0]
     assert np.array_equal(n2["refIndex"], interior)
     # boxes are the reference's, pre-digested: c = (a+b)*0.5f, h = f16(a-c), f16(b-c)
-    for side, child in (("L", interior + 1), ("R", nodes["right"][interior])):
+    for k, (side, child) in enumerate((("L", interior + 1), ("R", nodes["right"][interior]))):
         a, b = nodes["a"][child], nodes["b"][child]
         c = ((a + b) * np.float32(0.5)).astype(np.float32)
         assert np.array_equal(n2["c" + side], c)
         h = np.concatenate([(a - c).astype(np.float16), (b - c).astype(np.float16)], axis=1).view(np.uint16)
-        assert np.array_equal(n2["h" + side], h)
+        assert np.array_equal(n2["h"][:, :, k], h)
     # triangles inline, edges as fp32 differences
     assert np.array_equal(tr["i1"], ridx[:, 0].astype(np.int32))
     assert np.array_equal(tr["p1"], pos[ridx[:, 0], :3])
