@@ -21,11 +21,11 @@
 
 enum {
     CTR_NJOBS = 0,        /* entries of the current job list */
-    CTR_NSHADOW = 1,      /* shadow rays queued by the shade pass */
-    CTR_FETCH_CLOSEST = 2,
-    CTR_FETCH_SHADOW = 3,
-    CTR_COMPACT_OUT = 4,
-    CTR_LIVE = 5,         /* live jobs seen by the shade pass = closest-hit rays traced */
+    CTR_FETCH_CLOSEST = 1,
+    CTR_COMPACT_OUT = 2,
+    CTR_LIVE = 3,         /* live jobs seen by the shade pass = closest-hit rays traced */
+    CTR_NSHADOW = 4,      /* [2] shadow rays queued by the shade pass, one word per shadow queue */
+    CTR_FETCH_SHADOW = 6, /* [2] */
     CTR_WORDS = 8
 };
 
@@ -38,7 +38,9 @@ struct FrameArgs {
     uint32_t* jobsOut;
     uint32_t* ctr;
     const PtHitRec* hitRecs;
-    PtShadowRay* shadowRays;
+    PtShadowRay* shadowRays;         /* the shadow queue this depth appends to */
+    uint32_t shadowQueue;            /* 0 or 1: which counter word goes with it */
+    uint32_t fuseCompact;            /* shade appends surviving jobs to jobsOut instead of rewriting jobs in place */
     const PtVertexAux* aux;
     const PtLight* lights;
     const uint16_t* blueNoise;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
     uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
     const bool live = slot != PT_JOB_DEAD;
     bool wantShadow = false;
+    uint32_t nextJob = PT_JOB_DEAD;
     PtShadowRay sr;
 
     if (live) {
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
         const int32_t i1 = (int32_t)h0.y, i2 = (int32_t)h0.z, i3 = (int32_t)h0.w;
         if (i1 < 0) {                                                          /* trace.comp:192-196; the job ends here */
             s->prob = 0;
-            f.jobs[j] = PT_JOB_DEAD;
+            if (!f.fuseCompact) f.jobs[j] = PT_JOB_DEAD;
         } else {
             const float t = __uint_as_float(h0.x);
             const h16 bx = lo16(h1.x), by = hi16(h1.x), bz = lo16(h1.y);
@@ -194,9 +197,8 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
                 np[0] = make_float4(nextDir.x, nextDir.y, nextDir.z, __uint_as_float(rng.rnd));
                 np[1] = make_float4(hitPos.x, hitPos.y, hitPos.z, __uint_as_float(currentDepth + 1));
                 ((uint2*)(s + 1))[4] = make_uint2(0u, 0u);                     /* hitAlbedo = 0 */
-                f.jobs[j] = slot + 1;
+                nextJob = slot + 1;
             } else {                                                           /* trace.comp:224-227 */
-                f.jobs[j] = PT_JOB_DEAD;
                 if (f.zeroNextSlot && currentDepth != f.c.numRays - 1) (s + 1)->prob = 0;
             }
             s->randState = rng.rnd;                                            /* trace.comp:229-232 */
@@ -209,13 +211,28 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
         }
     }
 
-    /* wave-aggregated append to the shadow-ray queue, and the live-job count */
+    /* the job's next entry: in place (the reference's way, trace.comp:222-226) or appended to the next, dense list */
     const int lane = threadIdx.x & 63;
+    if (f.fuseCompact) {
+        const bool cont = nextJob != PT_JOB_DEAD;
+        uint64_t cm = __ballot(cont);
+        if (cm) {
+            int leader = __ffsll((unsigned long long)cm) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(f.ctr + CTR_COMPACT_OUT, (uint32_t)__popcll(cm));
+            base = __shfl(base, leader);
+            if (cont) f.jobsOut[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] = nextJob;
+        }
+    } else if (live && wantShadow) {
+        f.jobs[j] = nextJob;
+    }
+
+    /* wave-aggregated append to the shadow-ray queue, and the live-job count */
     uint64_t m = __ballot(wantShadow);
     if (m) {
         int leader = __ffsll((unsigned long long)m) - 1;
         uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(f.ctr + CTR_NSHADOW, (uint32_t)__popcll(m));
+        if (lane == leader) base = atomicAdd(f.ctr + CTR_NSHADOW + f.shadowQueue, (uint32_t)__popcll(m));
         base = __shfl(base, leader);
         if (wantShadow) {
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
@@ -233,7 +250,8 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
 __global__ void k_record_counts(FrameArgs f, uint32_t depthIndex)
 {
     f.rayCounts[2 * depthIndex] += f.ctr[CTR_LIVE];
-    f.rayCounts[2 * depthIndex + 1] += f.ctr[CTR_NSHADOW];
+    f.rayCounts[2 * depthIndex + 1] += f.ctr[CTR_NSHADOW + f.shadowQueue];
+    if (f.fuseCompact) f.ctr[CTR_NJOBS] = f.ctr[CTR_COMPACT_OUT];
 }
 
 /* Stream compaction of the job list (the role of raysort.comp:23-55, over the whole list instead of

@@ -55,8 +55,9 @@ bool load_nccl(std::string& err)
 
 struct PtContext {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;      /* stream2: shadow rays of depth d beside the closest-hit pass of depth d+1 */
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evShade[2] = { nullptr, nullptr }, evShadow[2] = { nullptr, nullptr };
+    bool shadowBusy[2] = { false, false };
     std::string err;
     int numCUs = 0;
 
@@ -71,7 +72,7 @@ struct PtContext {
     /* per-resolution (bindings 5,6,9,10) */
     uint32_t W = 0, H = 0, slots = 0;
     PtRayStackSlot* dStack = nullptr; uint32_t* dJobs[2] = { nullptr, nullptr }; int curJobs = 0;
-    PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow = nullptr; float4* dAccum = nullptr; uint2* dCurrent = nullptr;
+    PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow[2] = { nullptr, nullptr }; float4* dAccum = nullptr; uint2* dCurrent = nullptr;
     uint32_t* dCtr = nullptr; unsigned long long* dStats = nullptr; unsigned long long* dRayCounts = nullptr;
 
     PtShaderConstants consts; bool haveConsts = false;
@@ -100,7 +101,7 @@ void free_scene(PtContext* c)
 }
 void free_frame(PtContext* c)
 {
-    dfree(c->dStack); dfree(c->dJobs[0]); dfree(c->dJobs[1]); dfree(c->dHitRecs); dfree(c->dShadow); dfree(c->dAccum); dfree(c->dCurrent);
+    dfree(c->dStack); dfree(c->dJobs[0]); dfree(c->dJobs[1]); dfree(c->dHitRecs); dfree(c->dShadow[0]); dfree(c->dShadow[1]); dfree(c->dAccum); dfree(c->dCurrent);
     c->W = c->H = c->slots = 0;
 }
 
@@ -113,7 +114,8 @@ int ensure_overflow(PtContext* ctx)
     if (need <= ctx->overflowEntries && lanes <= ctx->overflowLanes && (ctx->dOverflow || need == 0)) return 0;
     dfree(ctx->dOverflow);
     ctx->overflowEntries = need; ctx->overflowLanes = lanes;
-    if (need) HIPCHK(hipMalloc((void**)&ctx->dOverflow, (size_t)need * lanes * sizeof(uint2)));
+    /* two areas: kernels on the two streams of pt_render_sample run side by side and must not share spill slots */
+    if (need) HIPCHK(hipMalloc((void**)&ctx->dOverflow, 2 * (size_t)need * lanes * sizeof(uint2)));
     return 0;
 }
 
@@ -127,26 +129,28 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     a.rootRef = (c->T == 1) ? PT_LEAF_BIT : 0u;
     a.overflow = c->dOverflow; a.overflowEntries = c->overflowEntries;
     a.refillMin = (uint32_t)c->optRefillMin;
-    a.stack = c->dStack; a.hitRecs = c->dHitRecs; a.shadowRays = c->dShadow;
+    a.stack = c->dStack; a.hitRecs = c->dHitRecs; a.shadowRays = c->dShadow[0];
     a.stats = c->dStats;
 }
 
 template <int MODE, bool ANYHIT>
-int launch_trace(PtContext* ctx, TraceArgs& a, bool count)
+int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream = nullptr)
 {
+    if (!stream) stream = ctx->stream;
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow; a.overflowEntries = ctx->overflowEntries;
+    if (stream == ctx->stream2 && ctx->dOverflow) a.overflow = ctx->dOverflow + (size_t)ctx->overflowEntries * ctx->overflowLanes;
     dim3 grid(grid_blocks(ctx)), block(PT_BLOCK);
     const int trav = ctx->optTraversal;
     if (trav == 0) {
-        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, ctx->stream, a);
+        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
     } else if (trav == 1) {
-        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, false, true>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, false, false>), grid, block, 0, ctx->stream, a);
+        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, false, false>), grid, block, 0, stream, a);
     } else {
-        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, true, true>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, true, false>), grid, block, 0, ctx->stream, a);
+        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, true, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, true, false>), grid, block, 0, stream, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -167,7 +171,7 @@ void fill_frame_args(PtContext* c, FrameArgs& f)
     f.c = c->consts; f.W = c->W; f.H = c->H; f.slots = c->slots;
     f.zeroNextSlot = c->optStale ? 0u : 1u; f.reseed = c->optReseed ? 1u : 0u;
     f.stack = c->dStack; f.jobs = c->dJobs[c->curJobs]; f.jobsOut = c->dJobs[c->curJobs ^ 1]; f.ctr = c->dCtr;
-    f.hitRecs = c->dHitRecs; f.shadowRays = c->dShadow; f.aux = c->dAux; f.lights = c->dLights; f.blueNoise = c->dBlueNoise;
+    f.hitRecs = c->dHitRecs; f.shadowRays = c->dShadow[0]; f.shadowQueue = 0; f.fuseCompact = 0; f.aux = c->dAux; f.lights = c->dLights; f.blueNoise = c->dBlueNoise;
     f.accumulation = c->dAccum; f.current = c->dCurrent; f.rayCounts = c->dRayCounts;
 }
 
@@ -193,7 +197,12 @@ PT_API int pt_ctx_create(int device_id, PtContext** out)
     ctx->device = device_id;
     ctx->numCUs = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->evShade[0], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->evShade[1], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->evShadow[0], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&ctx->evShadow[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc((void**)&ctx->dCtr, CTR_WORDS * 4)) != hipSuccess || (e = hipMalloc((void**)&ctx->dStats, 4 * 8)) != hipSuccess) {
         g_createError = hipGetErrorString(e);
         delete ctx;
@@ -210,11 +219,14 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(ctx->comm);
     free_scene(ctx); free_frame(ctx);
     dfree(ctx->dCtr); dfree(ctx->dStats); dfree(ctx->dRayCounts);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < 2; k++) { if (ctx->evShade[k]) (void)hipEventDestroy(ctx->evShade[k]); if (ctx->evShadow[k]) (void)hipEventDestroy(ctx->evShadow[k]); }
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -325,7 +337,8 @@ PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
     HIPCHK(hipMalloc((void**)&ctx->dJobs[0], px * 4));
     HIPCHK(hipMalloc((void**)&ctx->dJobs[1], px * 4));
     HIPCHK(hipMalloc((void**)&ctx->dHitRecs, px * sizeof(PtHitRec)));
-    HIPCHK(hipMalloc((void**)&ctx->dShadow, px * sizeof(PtShadowRay)));
+    HIPCHK(hipMalloc((void**)&ctx->dShadow[0], px * sizeof(PtShadowRay)));
+    HIPCHK(hipMalloc((void**)&ctx->dShadow[1], px * sizeof(PtShadowRay)));
     HIPCHK(hipMalloc((void**)&ctx->dAccum, px * 16));
     HIPCHK(hipMalloc((void**)&ctx->dCurrent, px * 8));
     HIPCHK(hipMalloc((void**)&ctx->dRayCounts, (size_t)2 * max_slots * 8));
@@ -373,15 +386,22 @@ PT_API int pt_launch(PtContext* ctx)
     return 0;
 }
 
-PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
+/* One depth of the frame.  overlapped = false: the three passes run in order on the context's stream and jobs are
+ * rewritten in place (what pt_trace promises).  overlapped = true (pt_render_sample): the shade pass also compacts
+ * the job list, and the shadow pass runs on the second stream beside the next depth's closest-hit pass; two shadow
+ * queues alternate, and a queue is reused only after the shadow pass that read it has finished. */
+static int trace_depth(PtContext* ctx, uint32_t depth, int speculative, bool overlapped)
 {
-    if (!ctx) return -1;
-    if (int rc = check_frame(ctx)) return rc;
-    if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_trace: scene was uploaded without vertex attributes or lights");
-    if (depth >= ctx->slots) return ctx->fail(-1, "pt_trace: depth exceeds the allocated slots");
-    if (speculative && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_trace: the speculative build needs W and H to be multiples of 8");
-    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_NSHADOW, 0, (CTR_WORDS - CTR_NSHADOW) * 4, ctx->stream));
+    const int q = overlapped ? (int)(depth & 1u) : 0;
+    if (ctx->shadowBusy[q]) {      /* queue q and its counters were last read by a shadow pass on stream2 */
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evShadow[q], 0));
+        ctx->shadowBusy[q] = false;
+    }
+    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_FETCH_CLOSEST, 0, 3 * 4, ctx->stream));              /* fetch, compact-out, live */
+    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_NSHADOW + q, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_FETCH_SHADOW + q, 0, 4, ctx->stream));
     FrameArgs f; fill_frame_args(ctx, f);
+    f.shadowRays = ctx->dShadow[q]; f.shadowQueue = (uint32_t)q; f.fuseCompact = overlapped ? 1u : 0u;
     TraceArgs a; fill_trace_args(ctx, a);
     a.jobs = f.jobs; a.countPtr = ctx->dCtr + CTR_NJOBS; a.fetchCounter = ctx->dCtr + CTR_FETCH_CLOSEST;
     if (speculative) {
@@ -394,13 +414,41 @@ PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
     }
     dim3 sgrid(((size_t)ctx->W * ctx->H + 255) / 256), sblock(256);
     hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, ctx->stream, f, depth);
-    HIPCHK(hipGetLastError());
-    TraceArgs s; fill_trace_args(ctx, s);
-    s.countPtr = ctx->dCtr + CTR_NSHADOW; s.fetchCounter = ctx->dCtr + CTR_FETCH_SHADOW;
-    if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false)) return rc;
     hipLaunchKernelGGL(k_record_counts, dim3(1), dim3(1), 0, ctx->stream, f, depth);
     HIPCHK(hipGetLastError());
+    if (overlapped) ctx->curJobs ^= 1;                                                      /* the shade pass wrote the next list */
+
+    TraceArgs s; fill_trace_args(ctx, s);
+    s.shadowRays = ctx->dShadow[q];
+    s.countPtr = ctx->dCtr + CTR_NSHADOW + q; s.fetchCounter = ctx->dCtr + CTR_FETCH_SHADOW + q;
+    if (overlapped) {
+        HIPCHK(hipEventRecord(ctx->evShade[q], ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->evShade[q], 0));
+        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, ctx->stream2)) return rc;
+        HIPCHK(hipEventRecord(ctx->evShadow[q], ctx->stream2));
+        ctx->shadowBusy[q] = true;
+    } else {
+        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false)) return rc;
+    }
     return 0;
+}
+
+/* Makes the context's stream wait for shadow passes still running on the second stream. */
+static int join_shadow(PtContext* ctx)
+{
+    for (int q = 0; q < 2; q++)
+        if (ctx->shadowBusy[q]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evShadow[q], 0)); ctx->shadowBusy[q] = false; }
+    return 0;
+}
+
+PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
+{
+    if (!ctx) return -1;
+    if (int rc = check_frame(ctx)) return rc;
+    if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_trace: scene was uploaded without vertex attributes or lights");
+    if (depth >= ctx->slots) return ctx->fail(-1, "pt_trace: depth exceeds the allocated slots");
+    if (speculative && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_trace: the speculative build needs W and H to be multiples of 8");
+    return trace_depth(ctx, depth, speculative, false);
 }
 
 PT_API int pt_compact(PtContext* ctx)
@@ -436,10 +484,11 @@ PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculativ
     if (ray_counts) HIPCHK(hipMemsetAsync(ctx->dRayCounts, 0, (size_t)2 * ctx->slots * 8, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     if (int rc = pt_launch(ctx)) return rc;
-    for (uint32_t d = 0; d < ctx->consts.numRays; d++) {                                    /* PathTracer.cpp:780-812 */
-        if (int rc = pt_trace(ctx, d, d == 0 && speculative_depth0)) return rc;
-        if (d != ctx->consts.numRays - 1) if (int rc = pt_compact(ctx)) return rc;
-    }
+    if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_render_sample: scene was uploaded without vertex attributes or lights");
+    if (speculative_depth0 && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_render_sample: the speculative build needs W and H to be multiples of 8");
+    for (uint32_t d = 0; d < ctx->consts.numRays; d++)                                      /* PathTracer.cpp:780-812 */
+        if (int rc = trace_depth(ctx, d, d == 0 && speculative_depth0, true)) return rc;
+    if (int rc = join_shadow(ctx)) return rc;
     if (int rc = pt_resolve_accumulate(ctx)) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->evPending = true;
