@@ -181,7 +181,11 @@ enum {
     PT_OPT_RESEED         = 3,   /* 0 = seed the LCG only after a clear (launch.comp:49-50, default);
                                     1 = reseed every frame (needed when frames are split over GPUs) */
     PT_OPT_PERSIST_BLOCKS = 4,   /* workgroups (256 lanes) per CU of the persistent traversal kernels */
-    PT_OPT_REFILL_MIN     = 5    /* a wavefront refills its idle lanes once this many of its 64 are idle */
+    PT_OPT_REFILL_MIN     = 5,   /* a wavefront refills its idle lanes once this many of its 64 are idle */
+    PT_OPT_CLAIM_CHUNK    = 6,   /* ray ids a wavefront takes from the global counter at a time: 0 = chosen from the
+                                    ray count (64..128), else 64..1024 in steps of 64 */
+    PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..4 (default 3): frames pt_render_samples keeps in flight, each on its own ray
+                                    stack and pair of streams; results do not depend on it */
 };
 PT_API int pt_set_option(PtContext* ctx, int option, int value);
 PT_API int pt_get_option(PtContext* ctx, int option, int* value);
@@ -218,6 +222,14 @@ PT_API int pt_resolve_accumulate(PtContext* ctx);                   /* PathTrace
  * uint64: closest-hit rays and shadow rays traced at each depth. */
 PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculative_depth0,
                             uint64_t* ray_counts);
+/* num_frames consecutive frames (frame_index = first, first+1, ...) with the constants last set.  The current
+ * image, the accumulation and every ray-stack slot the last frame's paths reached are what num_frames calls of
+ * pt_render_sample produce, byte for byte (slots beyond a path's end hold leftovers of an earlier frame, and
+ * which one depends on the number of frames in flight): a frame's launch pass takes each pixel's RNG state from the frame before it (launch.comp:49-50)
+ * and the accumulation adds run in frame order, but up to PT_OPT_FRAMES_IN_FLIGHT frames overlap on the GPU.
+ * With PT_OPT_STALE_SLOTS set the frames run one at a time.  ray_counts receives the sums over the frames. */
+PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames,
+                             int speculative_depth0, uint64_t* ray_counts);
 
 /* Replaces the dump read-back of PathTracer.cpp:848-854 (RGBA16F current image) and adds the
  * linear accumulation (RGBA32F, .w = sample count).  Host destination buffers. */
@@ -226,6 +238,27 @@ PT_API int pt_readback_accumulation(PtContext* ctx, float* rgba32f);
 PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob* jobs);
 PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const PtRayJob* jobs);
 PT_API void* pt_accumulation_device_ptr(PtContext* ctx);           /* 4 floats x W x H, for the all-reduce */
+
+/* Frame-dump interchange (PathTracer.cpp:180-202, 840-861): <dir>/RayStackBuffer_<index>.bin.z is one
+ * zlib stream of the W x H RGBA16F current image, <same>.txt holds "W,H".  pt_dump_current reads the
+ * current image back and writes the pair; pt_frame_dump_write / _read are the host-only halves
+ * (read with rgba16f == NULL only returns the size).  Note that the reference fills file <index> from the
+ * staging buffer it copied to a swapchain cycle earlier (:849 runs before :850 records the copy), so its
+ * file f holds the image of frame f - framesInFlight; here <index> is whatever the caller passes.
+ * Host-only calls return -1 bad argument, -4 file I/O, -5 zlib, -6 malformed size file or stream length,
+ * -7 destination too small. */
+PT_API int pt_dump_current(PtContext* ctx, const char* dir, uint32_t index);
+PT_API int pt_frame_dump_write(const char* dir, uint32_t index, uint32_t width, uint32_t height,
+                               const uint16_t* rgba16f);
+PT_API int pt_frame_dump_read(const char* dir, uint32_t index, uint32_t* width, uint32_t* height,
+                              uint16_t* rgba16f, uint64_t capacity_texels);
+
+/* Display colour of composite.frag:18-26,57, pow(ACESFilm(acc.rgb / acc.w), 1/2.2), computed on the GPU
+ * from the accumulation and copied to HOST buffers: rgb32f = 3 floats per pixel (the shader's outColor),
+ * rgba8 = 4 bytes per pixel (UNORM, round to nearest, alpha 255).  Either may be NULL.
+ * pt_write_ppm stores an rgba8 image as binary PPM (host only, codes as above). */
+PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8);
+PT_API int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8);
 
 /* Traversal microbench (no reference dispatch site; it calls traceRay, intersections.glsl:57-115,
  * on caller-supplied rays).  d_rays / d_hits are DEVICE pointers; stats, if not NULL, is a host

@@ -793,7 +793,7 @@ PO_API void po_raysort(PoFrame* f, const PtShaderConstants* c)
         }
 }
 
-/* composite.frag:30-55 (path resolve + accumulate; the tone-mapped display value of :57 is not part of the path) */
+/* composite.frag:30-55 (path resolve + accumulate; the display value of :57 is po_tonemap) */
 PO_API void po_composite(PoFrame* f, const PtShaderConstants* c)
 {
     const uint32_t W = (uint32_t)c->viewportSize[0], H = (uint32_t)c->viewportSize[1];
@@ -814,6 +814,20 @@ PO_API void po_composite(PoFrame* f, const PtShaderConstants* c)
             for (int k = 0; k < 3; k++) { f->current[4 * pix + k] = hbits(f2h(L[k])); f->accumulation[4 * pix + k] += L[k]; }
             f->current[4 * pix + 3] = hbits(f2h(1.0f));
             f->accumulation[4 * pix + 3] += 1.0f;
+        }
+}
+
+/* Display colour, composite.frag:18-26 (ACESFilm) and :57: pow(ACESFilm(acc.rgb / acc.w), 1/2.2), fp32.
+ * clamp(x,0,1) is min(max(x,0),1) with minNum/maxNum, so 0/0 shows as black. */
+PO_API void po_tonemap(const float* accumulation, uint64_t npix, float* rgb)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    for (uint64_t p = 0; p < npix; p++)
+        for (int k = 0; k < 3; k++) {
+            float x = accumulation[4 * p + k] / accumulation[4 * p + 3];
+            float v = (x * (a * x + b)) / (x * (c * x + d) + e);
+            v = fminf(fmaxf(v, 0.0f), 1.0f);
+            rgb[3 * p + k] = powf(v, 1.0f / 2.2f);
         }
 }
 

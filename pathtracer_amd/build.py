@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptcore.so")
-SOURCES = ["ptcore.hip", "bvh_build.cpp", "ply.cpp", "scene_prep.cpp"]
+SOURCES = ["ptcore.hip", "bvh_build.cpp", "ply.cpp", "scene_prep.cpp", "frame_dump.cpp"]
 HEADERS = ["device_math.h", "trace_kernels.h", "frame_kernels.h", "../../include/ptcore.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference's arithmetic is restated operation by operation; a fused
@@ -36,7 +36,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(path + ".o")
-    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-pthread"]
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-ldl", "-lz", "-pthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

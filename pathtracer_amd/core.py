@@ -30,7 +30,8 @@ CONST_DT = np.dtype([("viewMtx", "<f4", 16), ("projMtx", "<f4", 16), ("viewInvMt
 assert (NODE_DT.itemsize, NODE2_DT.itemsize, TRI_DT.itemsize, RAY_DT.itemsize, HIT_DT.itemsize) == (32, 64, 64, 32, 16)
 assert (LIGHT_DT.itemsize, AUX_DT.itemsize, SLOT_DT.itemsize, CONST_DT.itemsize) == (32, 16, 48, 320)
 
-OPT_TRAVERSAL, OPT_STALE_SLOTS, OPT_RESEED, OPT_PERSIST_BLOCKS, OPT_REFILL_MIN = 1, 2, 3, 4, 5
+OPT_TRAVERSAL, OPT_STALE_SLOTS, OPT_RESEED, OPT_PERSIST_BLOCKS, OPT_REFILL_MIN, OPT_CLAIM_CHUNK = 1, 2, 3, 4, 5, 6
+OPT_FRAMES_IN_FLIGHT = 7
 TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED = 0, 1, 2
 
 
@@ -84,11 +85,17 @@ def _load():
         "pt_compact": (i32, [vp]),
         "pt_resolve_accumulate": (i32, [vp]),
         "pt_render_sample": (i32, [vp, u32, i32, vp]),
+        "pt_render_samples": (i32, [vp, u32, u32, i32, vp]),
         "pt_readback_current": (i32, [vp, vp]),
         "pt_readback_accumulation": (i32, [vp, vp]),
         "pt_readback_raystack": (i32, [vp, vp, vp]),
         "pt_upload_raystack": (i32, [vp, vp, vp]),
         "pt_accumulation_device_ptr": (vp, [vp]),
+        "pt_dump_current": (i32, [vp, cp, u32]),
+        "pt_frame_dump_write": (i32, [cp, u32, u32, u32, vp]),
+        "pt_frame_dump_read": (i32, [cp, u32, pu32, pu32, vp, u64]),
+        "pt_tonemap": (i32, [vp, vp, vp]),
+        "pt_write_ppm": (i32, [cp, u32, u32, vp]),
         "pt_trace_rays": (i32, [vp, vp, u64, i32, vp, vp]),
         "pt_trace_rays_host": (i32, [vp, vp, u64, i32, vp, vp]),
         "pt_generate_rays": (i32, [vp, u64, u64, u64, vp]),
@@ -302,6 +309,12 @@ class PathTracer:
         self._chk(self._L.pt_render_sample(self._h, frame_index, int(speculative_depth0), _p(rc)))
         return rc
 
+    def render_samples(self, first_frame_index, num_frames, speculative_depth0=False, want_ray_counts=False):
+        """num_frames consecutive frames, several in flight; same results as that many render_sample calls."""
+        rc = np.zeros(2 * max(self.slots, 1), dtype=np.uint64) if want_ray_counts else None
+        self._chk(self._L.pt_render_samples(self._h, first_frame_index, num_frames, int(speculative_depth0), _p(rc)))
+        return rc
+
     # read-back --------------------------------------------------------------------------------
     def readback_accumulation(self):
         out = np.zeros((self.H, self.W, 4), dtype=np.float32)
@@ -326,6 +339,20 @@ class PathTracer:
 
     def accumulation_device_ptr(self):
         return self._L.pt_accumulation_device_ptr(self._h)
+
+    def dump_current(self, directory, index):
+        """Writes RayStackBuffer_<index>.bin.z (+ .txt) under directory (PathTracer.cpp:180-202, 840-861)."""
+        self._chk(self._L.pt_dump_current(self._h, os.fsencode(directory), index))
+
+    def tonemap(self, want_float=False):
+        """Display colour of composite.frag:57 as (H, W, 4) uint8, or (H, W, 3) float32 with want_float."""
+        if want_float:
+            out = np.zeros((self.H, self.W, 3), dtype=np.float32)
+            self._chk(self._L.pt_tonemap(self._h, _p(out), None))
+        else:
+            out = np.zeros((self.H, self.W, 4), dtype=np.uint8)
+            self._chk(self._L.pt_tonemap(self._h, None, _p(out)))
+        return out
 
     # traversal microbench ---------------------------------------------------------------------
     def alloc(self, nbytes):
@@ -366,3 +393,42 @@ def comm_unique_id():
     if L.pt_comm_unique_id(_p(uid)) != 0:
         raise PtError(L.pt_last_error(None).decode())
     return uid
+
+
+_HOST_CODES = {-1: "bad argument", -4: "file I/O error", -5: "zlib error", -6: "malformed size file or stream length",
+               -7: "destination too small"}
+
+
+def write_frame_dump(directory, index, rgba16f):
+    """Host half of the frame dump: rgba16f is (H, W, 4) uint16 (fp16 bit patterns) or float16."""
+    a = np.ascontiguousarray(rgba16f)
+    if a.dtype == np.float16:
+        a = a.view(np.uint16)
+    if a.dtype != np.uint16 or a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("rgba16f must be (H, W, 4) uint16 or float16")
+    rc = _load().pt_frame_dump_write(os.fsencode(directory), index, a.shape[1], a.shape[0], _p(a))
+    if rc:
+        raise PtError(f"pt_frame_dump_write: {_HOST_CODES.get(rc, rc)}")
+
+
+def read_frame_dump(directory, index):
+    """Reads a dump pair (this library's or the reference's) back as (H, W, 4) uint16."""
+    L = _load()
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    rc = L.pt_frame_dump_read(os.fsencode(directory), index, C.byref(w), C.byref(h), None, 0)
+    if rc:
+        raise PtError(f"pt_frame_dump_read: {_HOST_CODES.get(rc, rc)}")
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint16)
+    rc = L.pt_frame_dump_read(os.fsencode(directory), index, C.byref(w), C.byref(h), _p(out), out.size // 4)
+    if rc:
+        raise PtError(f"pt_frame_dump_read: {_HOST_CODES.get(rc, rc)}")
+    return out
+
+
+def write_ppm(path, rgba8):
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("rgba8 must be (H, W, 4) uint8")
+    rc = _load().pt_write_ppm(os.fsencode(path), a.shape[1], a.shape[0], _p(a))
+    if rc:
+        raise PtError(f"pt_write_ppm: {_HOST_CODES.get(rc, rc)}")

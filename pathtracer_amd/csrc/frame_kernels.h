@@ -24,22 +24,26 @@ enum {
     CTR_FETCH_CLOSEST = 1,
     CTR_COMPACT_OUT = 2,
     CTR_LIVE = 3,         /* live jobs seen by the shade pass = closest-hit rays traced */
-    CTR_NSHADOW = 4,      /* [2] shadow rays queued by the shade pass, one word per shadow queue */
-    CTR_FETCH_SHADOW = 6, /* [2] */
-    CTR_WORDS = 8
+    CTR_SHADOW = 4        /* then two words per depth: shadow rays queued by that depth's shade pass, and the shadow
+                             pass's fetch counter.  Per depth, so that nothing has to be cleared while a shadow pass
+                             of an earlier depth may still be running on the second stream. */
 };
+__host__ __device__ constexpr uint32_t ctr_words(uint32_t slots) { return CTR_SHADOW + 2u * slots; }
 
 struct FrameArgs {
     PtShaderConstants c;
     uint32_t W, H, slots;
     uint32_t zeroNextSlot, reseed;
+    uint32_t seedFromJitter;         /* launch: the accumulation holds no sample yet (launch.comp:49-50) */
     PtRayStackSlot* stack;
+    const PtRayStackSlot* rngStack;  /* launch: the stack whose slot 0 holds the RNG state the last frame left (with several
+                                        frames in flight that is another frame's stack) */
     uint32_t* jobs;
     uint32_t* jobsOut;
     uint32_t* ctr;
+    uint32_t* shadowCtr;             /* = ctr + CTR_SHADOW + 2*depth */
     const PtHitRec* hitRecs;
     PtShadowRay* shadowRays;         /* the shadow queue this depth appends to */
-    uint32_t shadowQueue;            /* 0 or 1: which counter word goes with it */
     uint32_t fuseCompact;            /* shade appends surviving jobs to jobsOut instead of rewriting jobs in place */
     const PtVertexAux* aux;
     const PtLight* lights;
@@ -59,7 +63,10 @@ __global__ __launch_bounds__(256) void k_launch(FrameArgs f)
 {
     const uint32_t gx = blockIdx.x * 32 + (threadIdx.x & 31), gy = blockIdx.y * 8 + (threadIdx.x >> 5);
     const uint32_t lx = gx + (uint32_t)f.c.viewportBase[0], ly = gy + (uint32_t)f.c.viewportBase[1];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) f.ctr[CTR_NJOBS] = f.W * f.H;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        f.ctr[CTR_NJOBS] = f.W * f.H;
+        for (uint32_t k = 1; k < ctr_words(f.slots); k++) f.ctr[k] = 0;            /* the frame starts from clean counters */
+    }
     if ((float)lx >= f.c.viewportSize[0] || (float)ly >= f.c.viewportSize[1]) return;
     uint32_t jitter = (uint32_t)f.blueNoise[(lx & 0xFF) + ((ly & 0xFF) << 8)] * 256u + (uint32_t)f.blueNoise[f.c.frameIndex & 0xFFFF];
     h16 wx, wy; WeylNth(jitter, wx, wy);
@@ -79,8 +86,8 @@ __global__ __launch_bounds__(256) void k_launch(FrameArgs f)
     PtRayStackSlot* s = f.stack + stackIndex;
     F3 d = { world[0] - cam[0], world[1] - cam[1], world[2] - cam[2] };
     float inv = 1.0f / __builtin_sqrtf(fdot(d, d));
-    uint32_t rs = s->randState;
-    if (f.reseed || f.accumulation[jobIndex].w < 0.5f) rs = jitter;
+    uint32_t rs = f.rngStack[stackIndex].randState;
+    if (f.reseed || f.seedFromJitter) rs = jitter;
     float4* sp = (float4*)s;
     sp[0] = make_float4(d.x * inv, d.y * inv, d.z * inv, __uint_as_float(rs));
     sp[1] = make_float4(cam[0], cam[1], cam[2], __uint_as_float(0u));
@@ -89,9 +96,10 @@ __global__ __launch_bounds__(256) void k_launch(FrameArgs f)
 }
 
 /* trace.comp:58-233 minus the two walks */
-__global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
+#define PT_SHADE_BLOCK 1024
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t depthIndex)
 {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t j = blockIdx.x * PT_SHADE_BLOCK + threadIdx.x;
     const uint32_t njobs = f.ctr[CTR_NJOBS];
     uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
     const bool live = slot != PT_JOB_DEAD;
@@ -211,47 +219,50 @@ __global__ __launch_bounds__(256) void k_shade(FrameArgs f, uint32_t depthIndex)
         }
     }
 
+    /* Counts go to the device counters once per workgroup (sixteen wavefronts): one atomic per wavefront on the same
+     * word serialises in one L2 channel and was the larger part of this kernel's time. */
+    __shared__ uint32_t shCount[3][PT_SHADE_BLOCK / 64];
+    __shared__ uint32_t shBase[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool cont = nextJob != PT_JOB_DEAD;
+    const uint64_t cm = __ballot(cont), m = __ballot(wantShadow), lm = __ballot(live);
+    if (lane == 0) { shCount[0][wave] = (uint32_t)__popcll(cm); shCount[1][wave] = (uint32_t)__popcll(m); shCount[2][wave] = (uint32_t)__popcll(lm); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot[3] = { 0, 0, 0 };
+        for (int w = 0; w < PT_SHADE_BLOCK / 64; w++)
+            for (int k = 0; k < 3; k++) { uint32_t c = shCount[k][w]; shCount[k][w] = tot[k]; tot[k] += c; }
+        shBase[0] = (f.fuseCompact && tot[0]) ? atomicAdd(f.ctr + CTR_COMPACT_OUT, tot[0]) : 0u;
+        shBase[1] = tot[1] ? atomicAdd(f.shadowCtr, tot[1]) : 0u;
+        if (tot[2]) atomicAdd(f.ctr + CTR_LIVE, tot[2]);
+    }
+    __syncthreads();
+
     /* the job's next entry: in place (the reference's way, trace.comp:222-226) or appended to the next, dense list */
-    const int lane = threadIdx.x & 63;
     if (f.fuseCompact) {
-        const bool cont = nextJob != PT_JOB_DEAD;
-        uint64_t cm = __ballot(cont);
-        if (cm) {
-            int leader = __ffsll((unsigned long long)cm) - 1;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(f.ctr + CTR_COMPACT_OUT, (uint32_t)__popcll(cm));
-            base = __shfl(base, leader);
-            if (cont) f.jobsOut[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] = nextJob;
-        }
+        if (cont) f.jobsOut[shBase[0] + shCount[0][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] = nextJob;
     } else if (live && wantShadow) {
         f.jobs[j] = nextJob;
     }
-
-    /* wave-aggregated append to the shadow-ray queue, and the live-job count */
-    uint64_t m = __ballot(wantShadow);
-    if (m) {
-        int leader = __ffsll((unsigned long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(f.ctr + CTR_NSHADOW + f.shadowQueue, (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
-        if (wantShadow) {
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-            const uint4* src = (const uint4*)&sr;
-            uint4* dst = (uint4*)(f.shadowRays + base + rank);
-            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-        }
+    if (wantShadow) {
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+        const uint4* src = (const uint4*)&sr;
+        uint4* dst = (uint4*)(f.shadowRays + shBase[1] + shCount[1][wave] + rank);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
     }
-    uint64_t lm = __ballot(live);
-    if (lm && lane == __ffsll((unsigned long long)lm) - 1) atomicAdd(f.ctr + CTR_LIVE, (uint32_t)__popcll(lm));
     (void)depthIndex;
 }
 
-/* Records the ray counts of one depth; one thread. */
+/* Records the ray counts of one depth; one thread.  With the fused compaction it also hands the new list length
+ * over and clears the counters the next depth's closest-hit and shade passes start from. */
 __global__ void k_record_counts(FrameArgs f, uint32_t depthIndex)
 {
     f.rayCounts[2 * depthIndex] += f.ctr[CTR_LIVE];
-    f.rayCounts[2 * depthIndex + 1] += f.ctr[CTR_NSHADOW + f.shadowQueue];
-    if (f.fuseCompact) f.ctr[CTR_NJOBS] = f.ctr[CTR_COMPACT_OUT];
+    f.rayCounts[2 * depthIndex + 1] += f.shadowCtr[0];
+    if (f.fuseCompact) {
+        f.ctr[CTR_NJOBS] = f.ctr[CTR_COMPACT_OUT];
+        f.ctr[CTR_FETCH_CLOSEST] = 0; f.ctr[CTR_COMPACT_OUT] = 0; f.ctr[CTR_LIVE] = 0;
+    }
 }
 
 /* Stream compaction of the job list (the role of raysort.comp:23-55, over the whole list instead of
@@ -301,6 +312,31 @@ __global__ __launch_bounds__(256) void k_resolve(FrameArgs f)
     float4 acc = f.accumulation[pix];
     acc.x += L[0]; acc.y += L[1]; acc.z += L[2]; acc.w += 1.0f;
     f.accumulation[pix] = acc;
+}
+
+/* Display colour of composite.frag:18-26,57: pow(ACESFilm(acc.rgb / acc.w), 1/2.2), fp32.  The reference
+ * writes it to the swapchain; here it goes to a float3 image (the shader's value) and/or an RGBA8 image
+ * (UNORM conversion: round to nearest, alpha 255).  clamp is min(max(x,0),1) with minNum/maxNum, so a
+ * pixel without samples (0/0) comes out black. */
+__device__ __forceinline__ float aces_film(float x)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    float v = (x * (a * x + b)) / (x * (c * x + d) + e);
+    return fminf(fmaxf(v, 0.0f), 1.0f);
+}
+__global__ __launch_bounds__(256) void k_tonemap(const float4* accumulation, uint32_t npix, float* rgb32f, uint32_t* rgba8)
+{
+    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= npix) return;
+    float4 acc = accumulation[pix];
+    float o[3] = { acc.x / acc.w, acc.y / acc.w, acc.z / acc.w };
+    uint32_t packed = 0xFF000000u;
+    for (int k = 0; k < 3; k++) {
+        o[k] = powf(aces_film(o[k]), 1.0f / 2.2f);
+        packed |= (uint32_t)rintf(o[k] * 255.0f) << (8 * k);
+    }
+    if (rgb32f) { rgb32f[3 * (size_t)pix + 0] = o[0]; rgb32f[3 * (size_t)pix + 1] = o[1]; rgb32f[3 * (size_t)pix + 2] = o[2]; }
+    if (rgba8) rgba8[pix] = packed;
 }
 
 /* Synthetic incoherent rays for the traversal microbench: five 24-bit uniforms per ray from

@@ -53,11 +53,29 @@ bool load_nccl(std::string& err)
 
 }  // namespace
 
+enum { PT_MAX_PIPES = 4 };
+
+/* Everything one frame in flight owns: its ray stack, job lists, hit records, shadow queues, counters, and the two
+ * streams its passes run on.  Pipe 0 serves the dispatch-site API and pt_render_sample; pt_render_samples deals
+ * frames round-robin to several pipes so that the short launches of one frame's deep bounces run beside the large
+ * launches of another's first bounces. */
+struct FramePipe {
+    int index = 0;
+    bool ready = false;
+    hipStream_t stream = nullptr, stream2 = nullptr;    /* stream2: shadow rays of depth d beside the closest-hit pass of depth d+1 */
+    hipEvent_t evShade[2] = { nullptr, nullptr }, evShadow[2] = { nullptr, nullptr };
+    hipEvent_t evShade0 = nullptr;                        /* slot 0 of the stack holds the frame's final RNG states */
+    hipEvent_t evDone = nullptr;                          /* the frame's resolve pass has run */
+    bool shadowBusy[2] = { false, false }, shade0Pending = false, donePending = false;
+    PtRayStackSlot* dStack = nullptr; uint32_t* dJobs[2] = { nullptr, nullptr }; int curJobs = 0;
+    PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow[2] = { nullptr, nullptr };
+    uint32_t* dCtr = nullptr; unsigned long long* dRayCounts = nullptr;
+};
+
 struct PtContext {
     int device = 0;
-    hipStream_t stream = nullptr, stream2 = nullptr;      /* stream2: shadow rays of depth d beside the closest-hit pass of depth d+1 */
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, evShade[2] = { nullptr, nullptr }, evShadow[2] = { nullptr, nullptr };
-    bool shadowBusy[2] = { false, false };
+    hipStream_t stream = nullptr;                         /* = pipe[0].stream: the stream the API's ordering promises refer to */
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evFork = nullptr;
     std::string err;
     int numCUs = 0;
 
@@ -66,17 +84,21 @@ struct PtContext {
     PtLight* dLights = nullptr; uint16_t* dBlueNoise = nullptr;
     uint4* dRecords = nullptr; uint2* dOverflow = nullptr; uint32_t leafBase = 0, recordBytes = 0;
     uint32_t V = 0, T = 0, N = 0, L = 0, maxStack = 0, overflowEntries = 0;
-    uint64_t overflowLanes = 0;
+    uint64_t overflowLanes = 0; int overflowAreas = 0;
     float rootBox[6] = {0}; float rootC[3] = {0}; uint16_t rootH[6] = {0};
 
     /* per-resolution (bindings 5,6,9,10) */
     uint32_t W = 0, H = 0, slots = 0;
-    PtRayStackSlot* dStack = nullptr; uint32_t* dJobs[2] = { nullptr, nullptr }; int curJobs = 0;
-    PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow[2] = { nullptr, nullptr }; float4* dAccum = nullptr; uint2* dCurrent = nullptr;
-    uint32_t* dCtr = nullptr; unsigned long long* dStats = nullptr; unsigned long long* dRayCounts = nullptr;
+    FramePipe pipe[PT_MAX_PIPES];
+    int rngPipe = 0;            /* the pipe whose stack holds the RNG states the next launch continues from (launch.comp:49-50) */
+    int lastPipe = 0;           /* the pipe of the most recent launch: what pt_readback_raystack returns */
+    int resolvePipe = 0;        /* the pipe of the most recent resolve pass: accumulation adds stay in frame order */
+    bool accumEmpty = true;     /* no sample in the accumulation since pt_resize / pt_clear_accumulation */
+    float4* dAccum = nullptr; uint2* dCurrent = nullptr;
+    uint32_t* dFetch = nullptr; unsigned long long* dStats = nullptr;      /* pt_trace_rays: id counter, visit statistics */
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3;
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
 
@@ -99,23 +121,36 @@ void free_scene(PtContext* c)
     dfree(c->dRecords); dfree(c->dOverflow);
     c->V = c->T = c->N = c->L = 0;
 }
+void free_pipe_buffers(FramePipe& p)
+{
+    dfree(p.dStack); dfree(p.dJobs[0]); dfree(p.dJobs[1]); dfree(p.dHitRecs); dfree(p.dShadow[0]); dfree(p.dShadow[1]);
+    dfree(p.dCtr); dfree(p.dRayCounts);
+    p.ready = false; p.curJobs = 0;
+    p.shadowBusy[0] = p.shadowBusy[1] = p.shade0Pending = p.donePending = false;
+}
 void free_frame(PtContext* c)
 {
-    dfree(c->dStack); dfree(c->dJobs[0]); dfree(c->dJobs[1]); dfree(c->dHitRecs); dfree(c->dShadow[0]); dfree(c->dShadow[1]); dfree(c->dAccum); dfree(c->dCurrent);
+    for (FramePipe& p : c->pipe) free_pipe_buffers(p);
+    dfree(c->dAccum); dfree(c->dCurrent);
     c->W = c->H = c->slots = 0;
+    c->rngPipe = c->lastPipe = c->resolvePipe = 0;
 }
 
 int grid_blocks(PtContext* c) { return c->numCUs * c->optBlocksPerCU; }
 
+/* Spill areas of the LDS stacks: one per traversal kernel that can be running at a time, that is two per pipe
+ * (closest-hit pass and shadow pass side by side). */
 int ensure_overflow(PtContext* ctx)
 {
     uint32_t need = ctx->maxStack > PT_STACK_LDS ? ctx->maxStack - PT_STACK_LDS : 0;
     uint64_t lanes = (uint64_t)grid_blocks(ctx) * PT_BLOCK;
-    if (need <= ctx->overflowEntries && lanes <= ctx->overflowLanes && (ctx->dOverflow || need == 0)) return 0;
+    int areas = 2;
+    for (int k = 1; k < PT_MAX_PIPES; k++) if (ctx->pipe[k].ready) areas = 2 * (k + 1);
+    if (need <= ctx->overflowEntries && lanes <= ctx->overflowLanes && areas <= ctx->overflowAreas && (ctx->dOverflow || need == 0)) return 0;
+    for (FramePipe& p : ctx->pipe) { if (p.stream) (void)hipStreamSynchronize(p.stream); if (p.stream2) (void)hipStreamSynchronize(p.stream2); }
     dfree(ctx->dOverflow);
-    ctx->overflowEntries = need; ctx->overflowLanes = lanes;
-    /* two areas: kernels on the two streams of pt_render_sample run side by side and must not share spill slots */
-    if (need) HIPCHK(hipMalloc((void**)&ctx->dOverflow, 2 * (size_t)need * lanes * sizeof(uint2)));
+    ctx->overflowEntries = need; ctx->overflowLanes = lanes; ctx->overflowAreas = areas;
+    if (need) HIPCHK(hipMalloc((void**)&ctx->dOverflow, (size_t)areas * need * lanes * sizeof(uint2)));
     return 0;
 }
 
@@ -128,18 +163,17 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     for (int k = 0; k < 6; k++) a.rootH[k] = c->rootH[k];
     a.rootRef = (c->T == 1) ? PT_LEAF_BIT : 0u;
     a.overflow = c->dOverflow; a.overflowEntries = c->overflowEntries;
-    a.refillMin = (uint32_t)c->optRefillMin;
-    a.stack = c->dStack; a.hitRecs = c->dHitRecs; a.shadowRays = c->dShadow[0];
+    a.refillMin = (uint32_t)c->optRefillMin; a.claimChunk = (uint32_t)c->optClaimChunk;
     a.stats = c->dStats;
 }
 
+/* area: which spill area the launch may use (2*pipe for the pipe's first stream, 2*pipe+1 for its second) */
 template <int MODE, bool ANYHIT>
-int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream = nullptr)
+int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, int area)
 {
-    if (!stream) stream = ctx->stream;
     if (int rc = ensure_overflow(ctx)) return rc;
-    a.overflow = ctx->dOverflow; a.overflowEntries = ctx->overflowEntries;
-    if (stream == ctx->stream2 && ctx->dOverflow) a.overflow = ctx->dOverflow + (size_t)ctx->overflowEntries * ctx->overflowLanes;
+    a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
+    a.overflowEntries = ctx->overflowEntries;
     dim3 grid(grid_blocks(ctx)), block(PT_BLOCK);
     const int trav = ctx->optTraversal;
     if (trav == 0) {
@@ -165,14 +199,72 @@ int check_frame(PtContext* ctx)
     return 0;
 }
 
-void fill_frame_args(PtContext* c, FrameArgs& f)
+void fill_frame_args(PtContext* c, FramePipe& p, FrameArgs& f, uint32_t depth = 0)
 {
     memset(&f, 0, sizeof(f));
     f.c = c->consts; f.W = c->W; f.H = c->H; f.slots = c->slots;
-    f.zeroNextSlot = c->optStale ? 0u : 1u; f.reseed = c->optReseed ? 1u : 0u;
-    f.stack = c->dStack; f.jobs = c->dJobs[c->curJobs]; f.jobsOut = c->dJobs[c->curJobs ^ 1]; f.ctr = c->dCtr;
-    f.hitRecs = c->dHitRecs; f.shadowRays = c->dShadow[0]; f.shadowQueue = 0; f.fuseCompact = 0; f.aux = c->dAux; f.lights = c->dLights; f.blueNoise = c->dBlueNoise;
-    f.accumulation = c->dAccum; f.current = c->dCurrent; f.rayCounts = c->dRayCounts;
+    f.zeroNextSlot = c->optStale ? 0u : 1u; f.reseed = c->optReseed ? 1u : 0u; f.seedFromJitter = c->accumEmpty ? 1u : 0u;
+    f.stack = p.dStack; f.rngStack = c->pipe[c->rngPipe].dStack;
+    f.jobs = p.dJobs[p.curJobs]; f.jobsOut = p.dJobs[p.curJobs ^ 1]; f.ctr = p.dCtr; f.shadowCtr = p.dCtr + CTR_SHADOW + 2 * depth;
+    f.hitRecs = p.dHitRecs; f.shadowRays = p.dShadow[0]; f.fuseCompact = 0; f.aux = c->dAux; f.lights = c->dLights; f.blueNoise = c->dBlueNoise;
+    f.accumulation = c->dAccum; f.current = c->dCurrent; f.rayCounts = p.dRayCounts;
+}
+
+/* Streams, events and buffers of pipe k at the current resolution. */
+int ensure_pipe(PtContext* ctx, int k)
+{
+    FramePipe& p = ctx->pipe[k];
+    p.index = k;
+    if (!p.stream) {
+        if (k == 0) p.stream = ctx->stream;
+        else HIPCHK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&p.stream2, hipStreamNonBlocking));
+        for (int q = 0; q < 2; q++) {
+            HIPCHK(hipEventCreateWithFlags(&p.evShade[q], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p.evShadow[q], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&p.evShade0, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming));
+    }
+    if (p.ready) return 0;
+    const size_t px = (size_t)ctx->W * ctx->H;
+    HIPCHK(hipMalloc((void**)&p.dStack, px * ctx->slots * sizeof(PtRayStackSlot)));
+    HIPCHK(hipMalloc((void**)&p.dJobs[0], px * 4));
+    HIPCHK(hipMalloc((void**)&p.dJobs[1], px * 4));
+    HIPCHK(hipMalloc((void**)&p.dHitRecs, px * sizeof(PtHitRec)));
+    HIPCHK(hipMalloc((void**)&p.dShadow[0], px * sizeof(PtShadowRay)));
+    HIPCHK(hipMalloc((void**)&p.dShadow[1], px * sizeof(PtShadowRay)));
+    HIPCHK(hipMalloc((void**)&p.dCtr, (size_t)ctr_words(ctx->slots) * 4));
+    HIPCHK(hipMalloc((void**)&p.dRayCounts, (size_t)2 * ctx->slots * 8));
+    /* the reference leaves these undefined; zero makes the first frame deterministic */
+    HIPCHK(hipMemset(p.dStack, 0, px * ctx->slots * sizeof(PtRayStackSlot)));
+    HIPCHK(hipMemset(p.dJobs[0], 0xFF, px * 4));
+    HIPCHK(hipMemset(p.dJobs[1], 0xFF, px * 4));
+    HIPCHK(hipMemset(p.dCtr, 0, (size_t)ctr_words(ctx->slots) * 4));
+    HIPCHK(hipMemset(p.dRayCounts, 0, (size_t)2 * ctx->slots * 8));
+    p.ready = true; p.curJobs = 0;
+    return 0;
+}
+
+void destroy_pipe(PtContext* ctx, FramePipe& p)
+{
+    free_pipe_buffers(p);
+    for (int q = 0; q < 2; q++) { if (p.evShade[q]) (void)hipEventDestroy(p.evShade[q]); if (p.evShadow[q]) (void)hipEventDestroy(p.evShadow[q]); }
+    if (p.evShade0) (void)hipEventDestroy(p.evShade0);
+    if (p.evDone) (void)hipEventDestroy(p.evDone);
+    if (p.stream2) (void)hipStreamDestroy(p.stream2);
+    if (p.stream && p.stream != ctx->stream) (void)hipStreamDestroy(p.stream);
+    p = FramePipe();
+}
+
+int sync_all(PtContext* ctx)
+{
+    for (FramePipe& p : ctx->pipe) {
+        if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
+        if (p.stream2) HIPCHK(hipStreamSynchronize(p.stream2));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
 }
 
 }  // namespace
@@ -197,18 +289,13 @@ PT_API int pt_ctx_create(int device_id, PtContext** out)
     ctx->device = device_id;
     ctx->numCUs = prop.multiProcessorCount;
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->evShade[0], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->evShade[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->evShadow[0], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&ctx->evShadow[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc((void**)&ctx->dCtr, CTR_WORDS * 4)) != hipSuccess || (e = hipMalloc((void**)&ctx->dStats, 4 * 8)) != hipSuccess) {
+        (e = hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->dFetch, 4)) != hipSuccess || (e = hipMalloc((void**)&ctx->dStats, 4 * 8)) != hipSuccess) {
         g_createError = hipGetErrorString(e);
-        delete ctx;
+        pt_ctx_destroy(ctx);
         return -10;
     }
-    (void)hipMemset(ctx->dCtr, 0, CTR_WORDS * 4);
     memset(&ctx->consts, 0, sizeof(ctx->consts));
     *out = ctx;
     return 0;
@@ -218,15 +305,14 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    (void)sync_all(ctx);
     if (ctx->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(ctx->comm);
     free_scene(ctx); free_frame(ctx);
-    dfree(ctx->dCtr); dfree(ctx->dStats); dfree(ctx->dRayCounts);
+    for (FramePipe& p : ctx->pipe) destroy_pipe(ctx, p);
+    dfree(ctx->dFetch); dfree(ctx->dStats);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    for (int k = 0; k < 2; k++) { if (ctx->evShade[k]) (void)hipEventDestroy(ctx->evShade[k]); if (ctx->evShadow[k]) (void)hipEventDestroy(ctx->evShadow[k]); }
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -250,6 +336,8 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_RESEED: ctx->optReseed = value != 0; return 0;
         case PT_OPT_PERSIST_BLOCKS: if (value < 1 || value > 8) return ctx->fail(-1, "PT_OPT_PERSIST_BLOCKS must be 1..8"); ctx->optBlocksPerCU = value; return 0;
         case PT_OPT_REFILL_MIN: if (value < 1 || value > 64) return ctx->fail(-1, "PT_OPT_REFILL_MIN must be 1..64"); ctx->optRefillMin = value; return 0;
+        case PT_OPT_CLAIM_CHUNK: if (value < 0 || value > 1024 || value % 64) return ctx->fail(-1, "PT_OPT_CLAIM_CHUNK must be 0 or a multiple of 64 up to 1024"); ctx->optClaimChunk = value; return 0;
+        case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..4"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
 }
@@ -262,6 +350,8 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_RESEED: *value = ctx->optReseed; return 0;
         case PT_OPT_PERSIST_BLOCKS: *value = ctx->optBlocksPerCU; return 0;
         case PT_OPT_REFILL_MIN: *value = ctx->optRefillMin; return 0;
+        case PT_OPT_CLAIM_CHUNK: *value = ctx->optClaimChunk; return 0;
+        case PT_OPT_FRAMES_IN_FLIGHT: *value = ctx->optFramesInFlight; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
 }
@@ -278,7 +368,7 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
         if (nodes[i].right <= 0 && ((uint32_t)(-nodes[i].right) % 3 != 0 || (uint32_t)(-nodes[i].right) / 3 >= T)) return ctx->fail(-1, "pt_scene_upload: leaf offset out of range");
     }
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     free_scene(ctx);
 
     std::vector<PtNode2> n2(T > 1 ? T - 1 : 1);
@@ -329,28 +419,16 @@ PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
     if (W == 0 || H == 0 || max_slots == 0) return ctx->fail(-1, "pt_resize: zero dimension");
     if ((uint64_t)W * H * max_slots >= 0xFFFFFFFFull) return ctx->fail(-1, "pt_resize: W*H*slots must fit a 32-bit slot index");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (int rc = sync_all(ctx)) return rc;
     free_frame(ctx);
-    dfree(ctx->dRayCounts);
     size_t px = (size_t)W * H;
-    HIPCHK(hipMalloc((void**)&ctx->dStack, px * max_slots * sizeof(PtRayStackSlot)));
-    HIPCHK(hipMalloc((void**)&ctx->dJobs[0], px * 4));
-    HIPCHK(hipMalloc((void**)&ctx->dJobs[1], px * 4));
-    HIPCHK(hipMalloc((void**)&ctx->dHitRecs, px * sizeof(PtHitRec)));
-    HIPCHK(hipMalloc((void**)&ctx->dShadow[0], px * sizeof(PtShadowRay)));
-    HIPCHK(hipMalloc((void**)&ctx->dShadow[1], px * sizeof(PtShadowRay)));
+    ctx->W = W; ctx->H = H; ctx->slots = max_slots;
     HIPCHK(hipMalloc((void**)&ctx->dAccum, px * 16));
     HIPCHK(hipMalloc((void**)&ctx->dCurrent, px * 8));
-    HIPCHK(hipMalloc((void**)&ctx->dRayCounts, (size_t)2 * max_slots * 8));
-    /* the reference leaves these undefined; zero makes the first frame deterministic */
-    HIPCHK(hipMemset(ctx->dStack, 0, px * max_slots * sizeof(PtRayStackSlot)));
-    HIPCHK(hipMemset(ctx->dJobs[0], 0xFF, px * 4));
-    HIPCHK(hipMemset(ctx->dJobs[1], 0xFF, px * 4));
     HIPCHK(hipMemset(ctx->dAccum, 0, px * 16));
     HIPCHK(hipMemset(ctx->dCurrent, 0, px * 8));
-    HIPCHK(hipMemset(ctx->dRayCounts, 0, (size_t)2 * max_slots * 8));
-    HIPCHK(hipMemset(ctx->dCtr, 0, CTR_WORDS * 4));
-    ctx->W = W; ctx->H = H; ctx->slots = max_slots; ctx->curJobs = 0;
+    ctx->accumEmpty = true;
+    if (int rc = ensure_pipe(ctx, 0)) { free_frame(ctx); return rc; }      /* further pipes come with the first pt_render_samples */
     return 0;
 }
 
@@ -370,6 +448,24 @@ PT_API int pt_clear_accumulation(PtContext* ctx)
     if (!ctx) return -1;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     HIPCHK(hipMemsetAsync(ctx->dAccum, 0, (size_t)ctx->W * ctx->H * 16, ctx->stream));
+    ctx->accumEmpty = true;
+    return 0;
+}
+
+/* launch.comp on pipe p.  The RNG state a pixel continues from lives in slot 0 of the stack the previous frame ran
+ * on; when that is another pipe's, this pipe's stream first waits for that frame's depth-0 shade pass, after which
+ * nothing writes those states any more. */
+static int launch_on(PtContext* ctx, FramePipe& p)
+{
+    if (!ctx->dBlueNoise) return ctx->fail(-2, "pt_launch: scene was uploaded without a blue-noise table");
+    FramePipe& src = ctx->pipe[ctx->rngPipe];
+    if (&src != &p && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(p.stream, src.evShade0, 0));
+    p.curJobs = 0;
+    FrameArgs f; fill_frame_args(ctx, p, f);
+    dim3 grid((ctx->W + 31) / 32, (ctx->H + 7) / 8), block(256);
+    hipLaunchKernelGGL(k_launch, grid, block, 0, p.stream, f);
+    HIPCHK(hipGetLastError());
+    ctx->rngPipe = ctx->lastPipe = p.index;
     return 0;
 }
 
@@ -377,67 +473,66 @@ PT_API int pt_launch(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = check_frame(ctx)) return rc;
-    if (!ctx->dBlueNoise) return ctx->fail(-2, "pt_launch: scene was uploaded without a blue-noise table");
-    ctx->curJobs = 0;
-    FrameArgs f; fill_frame_args(ctx, f);
-    dim3 grid((ctx->W + 31) / 32, (ctx->H + 7) / 8), block(256);
-    hipLaunchKernelGGL(k_launch, grid, block, 0, ctx->stream, f);
-    HIPCHK(hipGetLastError());
+    return launch_on(ctx, ctx->pipe[0]);
+}
+
+/* Makes the pipe's first stream wait for shadow passes still running on its second stream. */
+static int join_shadow(PtContext* ctx, FramePipe& p)
+{
+    for (int q = 0; q < 2; q++)
+        if (p.shadowBusy[q]) { HIPCHK(hipStreamWaitEvent(p.stream, p.evShadow[q], 0)); p.shadowBusy[q] = false; }
     return 0;
 }
 
-/* One depth of the frame.  overlapped = false: the three passes run in order on the context's stream and jobs are
- * rewritten in place (what pt_trace promises).  overlapped = true (pt_render_sample): the shade pass also compacts
- * the job list, and the shadow pass runs on the second stream beside the next depth's closest-hit pass; two shadow
- * queues alternate, and a queue is reused only after the shadow pass that read it has finished. */
-static int trace_depth(PtContext* ctx, uint32_t depth, int speculative, bool overlapped)
+/* One depth of the frame on pipe p.  overlapped = false: the three passes run in order on the pipe's first stream and
+ * jobs are rewritten in place (what pt_trace promises).  overlapped = true (pt_render_sample[s]): the shade pass also
+ * compacts the job list, and the shadow pass runs on the second stream beside the next depth's closest-hit pass; two
+ * shadow queues alternate, and a queue is rewritten only after the shadow pass that read it has finished. */
+static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int speculative, bool overlapped)
 {
     const int q = overlapped ? (int)(depth & 1u) : 0;
-    if (ctx->shadowBusy[q]) {      /* queue q and its counters were last read by a shadow pass on stream2 */
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evShadow[q], 0));
-        ctx->shadowBusy[q] = false;
-    }
-    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_FETCH_CLOSEST, 0, 3 * 4, ctx->stream));              /* fetch, compact-out, live */
-    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_NSHADOW + q, 0, 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_FETCH_SHADOW + q, 0, 4, ctx->stream));
-    FrameArgs f; fill_frame_args(ctx, f);
-    f.shadowRays = ctx->dShadow[q]; f.shadowQueue = (uint32_t)q; f.fuseCompact = overlapped ? 1u : 0u;
+    uint32_t* shadowCtr = p.dCtr + CTR_SHADOW + 2 * depth;
+    if (!overlapped) {
+        if (int rc = join_shadow(ctx, p)) return rc;
+        HIPCHK(hipMemsetAsync(p.dCtr + CTR_FETCH_CLOSEST, 0, 3 * 4, p.stream));                 /* fetch, compact-out, live */
+        HIPCHK(hipMemsetAsync(shadowCtr, 0, 2 * 4, p.stream));
+    }   /* overlapped: k_launch cleared every counter, k_record_counts clears the first three after each depth */
+    FrameArgs f; fill_frame_args(ctx, p, f, depth);
+    f.shadowRays = p.dShadow[q]; f.fuseCompact = overlapped ? 1u : 0u;
     TraceArgs a; fill_trace_args(ctx, a);
-    a.jobs = f.jobs; a.countPtr = ctx->dCtr + CTR_NJOBS; a.fetchCounter = ctx->dCtr + CTR_FETCH_CLOSEST;
+    a.stack = p.dStack; a.hitRecs = p.dHitRecs;
+    a.jobs = f.jobs; a.countPtr = p.dCtr + CTR_NJOBS; a.fetchCounter = p.dCtr + CTR_FETCH_CLOSEST;
     if (speculative) {
         /* needs the job list in pixel order, which holds right after pt_launch */
         dim3 grid(ctx->W / 8, ctx->H / 8), block(64);
-        hipLaunchKernelGGL(k_trace_ref_speculative, grid, block, 0, ctx->stream, a, ctx->W, ctx->H);
+        hipLaunchKernelGGL(k_trace_ref_speculative, grid, block, 0, p.stream, a, ctx->W, ctx->H);
         HIPCHK(hipGetLastError());
     } else {
-        if (int rc = launch_trace<MODE_JOBS, false>(ctx, a, false)) return rc;
+        if (int rc = launch_trace<MODE_JOBS, false>(ctx, a, false, p.stream, 2 * p.index)) return rc;
     }
-    dim3 sgrid(((size_t)ctx->W * ctx->H + 255) / 256), sblock(256);
-    hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, ctx->stream, f, depth);
-    hipLaunchKernelGGL(k_record_counts, dim3(1), dim3(1), 0, ctx->stream, f, depth);
+    if (p.shadowBusy[q]) {         /* the shade pass rewrites queue q: the shadow pass of depth-2 must be through with it */
+        HIPCHK(hipStreamWaitEvent(p.stream, p.evShadow[q], 0));
+        p.shadowBusy[q] = false;
+    }
+    dim3 sgrid(((size_t)ctx->W * ctx->H + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock(PT_SHADE_BLOCK);
+    hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, p.stream, f, depth);
+    hipLaunchKernelGGL(k_record_counts, dim3(1), dim3(1), 0, p.stream, f, depth);
     HIPCHK(hipGetLastError());
-    if (overlapped) ctx->curJobs ^= 1;                                                      /* the shade pass wrote the next list */
+    if (overlapped) p.curJobs ^= 1;                                                         /* the shade pass wrote the next list */
+    if (depth == 0) { HIPCHK(hipEventRecord(p.evShade0, p.stream)); p.shade0Pending = true; }
 
     TraceArgs s; fill_trace_args(ctx, s);
-    s.shadowRays = ctx->dShadow[q];
-    s.countPtr = ctx->dCtr + CTR_NSHADOW + q; s.fetchCounter = ctx->dCtr + CTR_FETCH_SHADOW + q;
+    s.stack = p.dStack; s.shadowRays = p.dShadow[q];
+    s.countPtr = shadowCtr; s.fetchCounter = shadowCtr + 1;
     if (overlapped) {
-        HIPCHK(hipEventRecord(ctx->evShade[q], ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->stream2, ctx->evShade[q], 0));
-        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, ctx->stream2)) return rc;
-        HIPCHK(hipEventRecord(ctx->evShadow[q], ctx->stream2));
-        ctx->shadowBusy[q] = true;
+        HIPCHK(hipEventRecord(p.evShade[q], p.stream));
+        HIPCHK(hipStreamWaitEvent(p.stream2, p.evShade[q], 0));
+        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, p.stream2, 2 * p.index + 1)) return rc;
+        HIPCHK(hipEventRecord(p.evShadow[q], p.stream2));
+        p.shadowBusy[q] = true;
     } else {
-        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false)) return rc;
+        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, p.stream, 2 * p.index)) return rc;
     }
-    return 0;
-}
-
-/* Makes the context's stream wait for shadow passes still running on the second stream. */
-static int join_shadow(PtContext* ctx)
-{
-    for (int q = 0; q < 2; q++)
-        if (ctx->shadowBusy[q]) { HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->evShadow[q], 0)); ctx->shadowBusy[q] = false; }
     return 0;
 }
 
@@ -448,20 +543,37 @@ PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
     if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_trace: scene was uploaded without vertex attributes or lights");
     if (depth >= ctx->slots) return ctx->fail(-1, "pt_trace: depth exceeds the allocated slots");
     if (speculative && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_trace: the speculative build needs W and H to be multiples of 8");
-    return trace_depth(ctx, depth, speculative, false);
+    return trace_depth(ctx, ctx->pipe[0], depth, speculative, false);
 }
 
 PT_API int pt_compact(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = check_frame(ctx)) return rc;
-    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_COMPACT_OUT, 0, 4, ctx->stream));
-    FrameArgs f; fill_frame_args(ctx, f);
+    FramePipe& p = ctx->pipe[0];
+    HIPCHK(hipMemsetAsync(p.dCtr + CTR_COMPACT_OUT, 0, 4, p.stream));
+    FrameArgs f; fill_frame_args(ctx, p, f);
     dim3 grid(((size_t)ctx->W * ctx->H + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_compact, grid, block, 0, ctx->stream, f);
-    hipLaunchKernelGGL(k_compact_finish, dim3(1), dim3(1), 0, ctx->stream, f);
+    hipLaunchKernelGGL(k_compact, grid, block, 0, p.stream, f);
+    hipLaunchKernelGGL(k_compact_finish, dim3(1), dim3(1), 0, p.stream, f);
     HIPCHK(hipGetLastError());
-    ctx->curJobs ^= 1;
+    p.curJobs ^= 1;
+    return 0;
+}
+
+/* composite.frag on pipe p.  Accumulation adds happen in frame order: the pass waits for the resolve pass of the
+ * frame before it when that ran on another pipe. */
+static int resolve_on(PtContext* ctx, FramePipe& p)
+{
+    if (int rc = join_shadow(ctx, p)) return rc;
+    FramePipe& prev = ctx->pipe[ctx->resolvePipe];
+    if (&prev != &p && prev.donePending) HIPCHK(hipStreamWaitEvent(p.stream, prev.evDone, 0));
+    FrameArgs f; fill_frame_args(ctx, p, f);
+    dim3 grid(((size_t)ctx->W * ctx->H + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_resolve, grid, block, 0, p.stream, f);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(p.evDone, p.stream)); p.donePending = true;
+    ctx->resolvePipe = p.index; ctx->accumEmpty = false;
     return 0;
 }
 
@@ -469,34 +581,62 @@ PT_API int pt_resolve_accumulate(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = check_frame(ctx)) return rc;
-    FrameArgs f; fill_frame_args(ctx, f);
-    dim3 grid(((size_t)ctx->W * ctx->H + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_resolve, grid, block, 0, ctx->stream, f);
-    HIPCHK(hipGetLastError());
+    return resolve_on(ctx, ctx->pipe[0]);
+}
+
+/* One frame (PathTracer.cpp:729-838) queued on pipe p. */
+static int frame_on(PtContext* ctx, FramePipe& p, uint32_t frame_index, int speculative_depth0)
+{
+    ctx->consts.frameIndex = frame_index & 0xFFFF;                                          /* PathTracer.cpp:729 */
+    if (int rc = launch_on(ctx, p)) return rc;
+    for (uint32_t d = 0; d < ctx->consts.numRays; d++)                                      /* PathTracer.cpp:780-812 */
+        if (int rc = trace_depth(ctx, p, d, d == 0 && speculative_depth0, true)) return rc;
+    return resolve_on(ctx, p);
+}
+
+PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, int speculative_depth0, uint64_t* ray_counts)
+{
+    if (!ctx) return -1;
+    if (int rc = check_frame(ctx)) return rc;
+    if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_render_sample: scene was uploaded without vertex attributes or lights");
+    if (speculative_depth0 && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_render_sample: the speculative build needs W and H to be multiples of 8");
+    if (num_frames == 0) return 0;
+    /* the reference's stale-slot behaviour needs every frame on the one ray stack */
+    int K = ctx->optStale ? 1 : ctx->optFramesInFlight;
+    if ((uint32_t)K > num_frames) K = (int)num_frames;
+    for (int k = 0; k < K; k++) if (int rc = ensure_pipe(ctx, k)) return rc;
+    if (int rc = ensure_overflow(ctx)) return rc;
+    const uint32_t nr = ctx->consts.numRays;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (K > 1) {       /* the other pipes start after whatever is already queued on the context's stream */
+        HIPCHK(hipEventRecord(ctx->evFork, ctx->stream));
+        for (int k = 1; k < K; k++) HIPCHK(hipStreamWaitEvent(ctx->pipe[k].stream, ctx->evFork, 0));
+    }
+    if (ray_counts) for (int k = 0; k < K; k++) HIPCHK(hipMemsetAsync(ctx->pipe[k].dRayCounts, 0, (size_t)2 * ctx->slots * 8, ctx->pipe[k].stream));
+    for (uint32_t i = 0; i < num_frames; i++)
+        if (int rc = frame_on(ctx, ctx->pipe[i % (uint32_t)K], first_frame_index + i, speculative_depth0)) return rc;
+    for (int k = 1; k < K; k++) {      /* join: later calls on the context's stream see every frame finished */
+        FramePipe& p = ctx->pipe[k];
+        if (p.donePending) { HIPCHK(hipStreamWaitEvent(ctx->stream, p.evDone, 0)); p.donePending = false; }
+        p.shade0Pending = false;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->evPending = true;
+    if (ray_counts) {
+        std::vector<uint64_t> part((size_t)2 * nr);
+        memset(ray_counts, 0, (size_t)2 * nr * 8);
+        for (int k = 0; k < K; k++) {
+            HIPCHK(hipMemcpyAsync(part.data(), ctx->pipe[k].dRayCounts, (size_t)2 * nr * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            for (uint32_t j = 0; j < 2 * nr; j++) ray_counts[j] += part[j];
+        }
+    }
     return 0;
 }
 
 PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculative_depth0, uint64_t* ray_counts)
 {
-    if (!ctx) return -1;
-    if (int rc = check_frame(ctx)) return rc;
-    ctx->consts.frameIndex = frame_index & 0xFFFF;                                          /* PathTracer.cpp:729 */
-    if (ray_counts) HIPCHK(hipMemsetAsync(ctx->dRayCounts, 0, (size_t)2 * ctx->slots * 8, ctx->stream));
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (int rc = pt_launch(ctx)) return rc;
-    if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_render_sample: scene was uploaded without vertex attributes or lights");
-    if (speculative_depth0 && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_render_sample: the speculative build needs W and H to be multiples of 8");
-    for (uint32_t d = 0; d < ctx->consts.numRays; d++)                                      /* PathTracer.cpp:780-812 */
-        if (int rc = trace_depth(ctx, d, d == 0 && speculative_depth0, true)) return rc;
-    if (int rc = join_shadow(ctx)) return rc;
-    if (int rc = pt_resolve_accumulate(ctx)) return rc;
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->evPending = true;
-    if (ray_counts) {
-        HIPCHK(hipMemcpyAsync(ray_counts, ctx->dRayCounts, (size_t)2 * ctx->consts.numRays * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return 0;
+    return pt_render_samples(ctx, frame_index, 1, speculative_depth0, ray_counts);
 }
 
 PT_API int pt_readback_current(PtContext* ctx, uint16_t* rgba16f)
@@ -520,8 +660,9 @@ PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob*
     if (!ctx) return -1;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
-    if (slots) HIPCHK(hipMemcpyAsync(slots, ctx->dStack, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyDeviceToHost, ctx->stream));
-    if (jobs) HIPCHK(hipMemcpyAsync(jobs, ctx->dJobs[ctx->curJobs], px * 4, hipMemcpyDeviceToHost, ctx->stream));
+    FramePipe& p = ctx->pipe[ctx->lastPipe];           /* the stack and job list of the most recent frame */
+    if (slots) HIPCHK(hipMemcpyAsync(slots, p.dStack, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyDeviceToHost, ctx->stream));
+    if (jobs) HIPCHK(hipMemcpyAsync(jobs, p.dJobs[p.curJobs], px * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -530,30 +671,63 @@ PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const
     if (!ctx) return -1;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
-    if (slots) HIPCHK(hipMemcpyAsync(ctx->dStack, slots, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyHostToDevice, ctx->stream));
+    FramePipe& p = ctx->pipe[0];                        /* the dispatch-site calls that follow work on pipe 0 */
+    if (slots) { HIPCHK(hipMemcpyAsync(p.dStack, slots, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyHostToDevice, ctx->stream)); ctx->rngPipe = 0; }
     if (jobs) {
         uint32_t n = (uint32_t)px;
-        HIPCHK(hipMemcpyAsync(ctx->dJobs[ctx->curJobs], jobs, px * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->dCtr + CTR_NJOBS, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(p.dJobs[p.curJobs], jobs, px * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(p.dCtr + CTR_NJOBS, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     }
+    ctx->lastPipe = 0;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 PT_API void* pt_accumulation_device_ptr(PtContext* ctx) { return ctx ? (void*)ctx->dAccum : nullptr; }
+
+PT_API int pt_dump_current(PtContext* ctx, const char* dir, uint32_t index)
+{
+    if (!ctx) return -1;
+    if (!ctx->W) return ctx->fail(-2, "no frame resources");
+    std::vector<uint16_t> img((size_t)ctx->W * ctx->H * 4);
+    if (int rc = pt_readback_current(ctx, img.data())) return rc;
+    int rc = pt_frame_dump_write(dir, index, ctx->W, ctx->H, img.data());
+    if (rc) return ctx->fail(rc, std::string("pt_dump_current: cannot write the dump pair under ") + (dir ? dir : "."));
+    return 0;
+}
+
+PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8)
+{
+    if (!ctx) return -1;
+    if (!ctx->W) return ctx->fail(-2, "no frame resources");
+    if (!rgb32f && !rgba8) return 0;
+    const size_t px = (size_t)ctx->W * ctx->H;
+    float* dF = nullptr; uint32_t* dB = nullptr;
+    if (rgb32f) HIPCHK(hipMalloc((void**)&dF, px * 12));
+    if (rgba8 && hipMalloc((void**)&dB, px * 4) != hipSuccess) { dfree(dF); return ctx->fail(-10, "pt_tonemap: out of device memory"); }
+    hipLaunchKernelGGL(k_tonemap, dim3((px + 255) / 256), dim3(256), 0, ctx->stream, ctx->dAccum, (uint32_t)px, dF, dB);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && rgb32f) e = hipMemcpyAsync(rgb32f, dF, px * 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && rgba8) e = hipMemcpyAsync(rgba8, dB, px * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    dfree(dF); dfree(dB);
+    if (e != hipSuccess) return ctx->fail(-10, std::string("pt_tonemap: ") + hipGetErrorString(e));
+    return 0;
+}
 
 PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits, uint64_t* stats)
 {
     if (!ctx) return -1;
     if (int rc = check_scene(ctx)) return rc;
     if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays: null buffer");
-    if (num_rays >= 0xFFFFFF00ull) return ctx->fail(-1, "pt_trace_rays: at most 2^32-256 rays per call");
+    /* the id counter is 32 bits wide and every wavefront may overshoot the count by one chunk */
+    if (num_rays > 0xFE000000ull) return ctx->fail(-1, "pt_trace_rays: at most 2^32-2^25 rays per call");
     if (num_rays == 0) return 0;
-    HIPCHK(hipMemsetAsync(ctx->dCtr + CTR_FETCH_CLOSEST, 0, 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->dFetch, 0, 4, ctx->stream));
     if (stats) HIPCHK(hipMemsetAsync(ctx->dStats, 0, 32, ctx->stream));
     TraceArgs a; fill_trace_args(ctx, a);
-    a.rays = d_rays; a.hits = d_hits; a.count = num_rays; a.countPtr = nullptr; a.fetchCounter = ctx->dCtr + CTR_FETCH_CLOSEST;
+    a.rays = d_rays; a.hits = d_hits; a.count = num_rays; a.countPtr = nullptr; a.fetchCounter = ctx->dFetch;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    int rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr);
+    int rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->evPending = true;

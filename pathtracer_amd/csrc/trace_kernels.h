@@ -72,6 +72,7 @@ struct TraceArgs {
     const uint32_t*  countPtr;       /* number of rays, read on the device (nullptr: use count) */
     uint64_t         count;
     uint32_t         refillMin;      /* refill a wavefront when this many lanes are idle */
+    uint32_t         claimChunk;     /* ids a wavefront takes from the counter at a time (0: chosen from the ray count) */
     /* MODE_RAYS */
     const PtRay*     rays;  PtHit* hits;
     /* MODE_JOBS */
@@ -142,18 +143,48 @@ __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, ui
     }
 }
 
-/* Claims ids for the idle lanes of this wavefront from the global counter.  Wave-uniform call. */
-__device__ __forceinline__ uint64_t claim_ids(uint32_t* counter, bool idle, uint64_t idleMask, int nIdle, uint64_t& waveEnd)
-{
-    const int lane = threadIdx.x & 63;
-    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0));
-    int leader = __ffsll((unsigned long long)idleMask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)nIdle);
-    base = __shfl(base, leader);
-    waveEnd = (uint64_t)base + (uint64_t)nIdle;
-    return idle ? (uint64_t)base + rank : ~0ull;
-}
+/* Ray ids for the idle lanes of a wavefront.  The wavefront draws ids from a private reserve and tops the reserve up
+ * from the global counter a chunk at a time (one atomic by one lane), so that thousands of wavefronts do not queue
+ * on one word for every refill.  All members are wave-uniform. */
+struct RayPool {
+    uint64_t next = 0, end = 0;      /* the reserve: ids [next, end) belong to this wavefront */
+    uint64_t total = 0;
+    uint32_t chunk = 64;
+    bool     drained = false;        /* the global counter has passed total: no more chunks */
+
+    __device__ __forceinline__ void init(const TraceArgs& a, uint64_t totalRays, uint32_t numWaves)
+    {
+        total = totalRays;
+        /* small launches keep the chunk at one wavefront's worth so that the rays spread over all wavefronts */
+        uint64_t per = totalRays / (numWaves ? numWaves : 1u);
+        uint32_t c = a.claimChunk ? a.claimChunk : (uint32_t)(per > 128 ? 128 : per);
+        chunk = c < 64 ? 64u : (c & ~63u);
+    }
+    __device__ __forceinline__ bool exhausted() const { return drained && next >= end; }
+
+    /* Wave-uniform call; returns this lane's new id, or ~0 if it gets none. */
+    __device__ __forceinline__ uint64_t claim(uint32_t* counter, bool idle, uint64_t idleMask, int nIdle)
+    {
+        const int lane = threadIdx.x & 63;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0));
+        const uint64_t avail = end - next;
+        uint64_t id = ~0ull;
+        if (avail >= (uint64_t)nIdle || drained) {
+            if (idle && rank < avail) id = next + rank;
+            next += avail < (uint64_t)nIdle ? avail : (uint64_t)nIdle;
+        } else {
+            const int leader = __ffsll((unsigned long long)idleMask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(counter, chunk);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl(base, leader));
+            if (idle) id = rank < avail ? next + rank : (uint64_t)base + (rank - avail);
+            next = (uint64_t)base + ((uint64_t)nIdle - avail);
+            end = (uint64_t)base + chunk;
+            if (end >= total) { end = end < total ? end : total; drained = true; if (next > end) next = end; }
+        }
+        return (id < total) ? id : ~0ull;
+    }
+};
 
 /* ---- reference-layout walk -------------------------------------------------------------------- */
 
@@ -161,7 +192,8 @@ template <int MODE, bool ANYHIT, bool COUNT>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref(TraceArgs a)
 {
     const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
-    bool active = false, exhausted = false;
+    RayPool pool; pool.init(a, total, gridDim.x * (PT_BLOCK / 64));
+    bool active = false;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     uint32_t index = 0, hitIndex = 0; bool hit = false;
     int32_t i1 = -1, i2 = -1, i3 = -1; float alpha = 0, beta = 0, gamma = 0;
@@ -170,12 +202,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref(TraceArgs a)
     for (;;) {
         uint64_t idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
-        if (nIdle == 64 && exhausted) break;
-        if (!exhausted && (nIdle >= (int)a.refillMin || nIdle == 64)) {
-            uint64_t waveEnd;
-            uint64_t nid = claim_ids(a.fetchCounter, !active, idleMask, nIdle, waveEnd);
-            if (waveEnd >= total) exhausted = true;
-            if (!active && nid < total) {
+        if (nIdle == 64 && pool.exhausted()) break;
+        if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
+            uint64_t nid = pool.claim(a.fetchCounter, !active, idleMask, nIdle);
+            if (!active && nid != ~0ull) {
                 id = nid;
                 if (load_ray<MODE>(a, id, r, exclude, tag)) {
                     active = true; index = 0; hitIndex = 0; hit = false; i1 = i2 = i3 = -1;
@@ -304,7 +334,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
 
-    bool active = false, exhausted = false;
+    RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
+    bool active = false;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;       /* rcpD duplicated into both halves */
     uint32_t cur = 0; int sp = 0;
@@ -323,12 +354,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         /* ---- refill idle lanes from the global ray pool ---- */
         uint64_t idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
-        if (nIdle == 64 && exhausted) break;
-        if (!exhausted && (nIdle >= (int)a.refillMin || nIdle == 64)) {
-            uint64_t waveEnd;
-            uint64_t nid = claim_ids(a.fetchCounter, !active, idleMask, nIdle, waveEnd);
-            if (waveEnd >= total) exhausted = true;
-            if (!active && nid < total) {
+        if (nIdle == 64 && pool.exhausted()) break;
+        if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
+            uint64_t nid = pool.claim(a.fetchCounter, !active, idleMask, nIdle);
+            if (!active && nid != ~0ull) {
                 id = nid;
                 if (load_ray<MODE>(a, id, r, exclude, tag)) {
                     if (COUNT) { nRay++; nBox++; }

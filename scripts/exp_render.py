@@ -12,6 +12,9 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--slots", type=int, default=8)
 ap.add_argument("--frames", type=int, default=20)
 ap.add_argument("--traversal", type=int, default=2)
+ap.add_argument("--inflight", type=int, default=2)
+ap.add_argument("--reseed", type=int, default=0)
+ap.add_argument("--blocks", type=int, default=5)
 args = ap.parse_args()
 if args.scene == "bunny":
     pos, aux, idx = pt.load_ply(os.path.join(ROOT, "tests", "golden", "models", "CBbunny.ply"))
@@ -29,17 +32,18 @@ ctx.set_option(core.OPT_TRAVERSAL, args.traversal)
 W, H, NR = args.width, args.height, args.slots
 ctx.resize(W, H, NR)
 ctx.set_constants(pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **cam))
-for f in range(1, 4):
-    ctx.render_sample(f)
+ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, args.inflight)
+ctx.set_option(core.OPT_RESEED, args.reseed)
+ctx.set_option(core.OPT_PERSIST_BLOCKS, args.blocks)
+ctx.render_samples(1, 3)
 ctx.synchronize()
 t = time.perf_counter()
-for f in range(4, 4 + args.frames):
-    ctx.render_sample(f)
+ctx.render_samples(4, args.frames)
 ctx.synchronize()
 dt = time.perf_counter() - t
 rc = ctx.render_sample(4 + args.frames, want_ray_counts=True)
 rays = int(rc[:2 * NR].sum())
-print(f"{args.scene} {W}x{H} slots {NR} traversal {args.traversal}: {args.frames/dt:.2f} spp/s, {dt/args.frames*1e3:.2f} ms/frame, rays/sample {rays}, {rays*args.frames/dt/1e6:.0f} Mrays/s")
+print(f"{args.scene} {W}x{H} slots {NR} traversal {args.traversal} in flight {args.inflight} blocks {args.blocks} reseed {args.reseed}: {args.frames/dt:.2f} spp/s, {dt/args.frames*1e3:.2f} ms/frame, rays/sample {rays}, {rays*args.frames/dt/1e6:.0f} Mrays/s")
 print("ray counts (closest, shadow) per depth:", rc[:2 * NR].reshape(-1, 2).tolist())
 acc = ctx.readback_accumulation()
 print("mean radiance", (acc[..., :3] / acc[..., 3:4]).mean(axis=(0, 1)))

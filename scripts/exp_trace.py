@@ -17,12 +17,15 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--blocks", type=str, default="6")
 ap.add_argument("--refill", type=str, default="24")
 ap.add_argument("--modes", type=str, default="0,1,2")
+ap.add_argument("--chunk", type=str, default="0")
 ap.add_argument("--scene", type=str, default="courtyard")
 args = ap.parse_args()
 
 t = time.time()
 if args.scene == "bunny":
     pos, aux, idx = pt.load_ply(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "models", "CBbunny.ply"))
+elif args.scene == "sanmiguel":
+    pos, aux, idx = pt.scenes.san_miguel_like(args.tris)
 else:
     pos, aux, idx = pt.scenes.courtyard(args.tris, seed=13)
 print(f"scene: {idx.shape[0]} tris, {pos.shape[0]} verts, gen {time.time()-t:.1f}s", flush=True)
@@ -48,7 +51,8 @@ for mode in [int(m) for m in args.modes.split(",")]:
     print(f"mode {mode}: box/ray {st[0]/n:.1f} tri/ray {st[1]/n:.2f} rec/ray {st[2]/n:.1f} hit rate {(hits['i1']>=0).mean():.3f} diff vs first mode {diff:.2e}", flush=True)
     for blocks in [int(b) for b in args.blocks.split(",")]:
         for refill in [int(r) for r in args.refill.split(",")]:
-          if True:
+          for chunk in [int(c) for c in args.chunk.split(",")]:
+            ctx.set_option(core.OPT_CLAIM_CHUNK, chunk)
             ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
             ctx.set_option(core.OPT_REFILL_MIN, refill)
             ms = []
@@ -56,6 +60,6 @@ for mode in [int(m) for m in args.modes.split(",")]:
                 ctx.trace_rays_device(d_rays, n, d_hits)
                 ms.append(ctx.last_kernel_ms())
             best = min(ms)
-            print(f"   blocks/CU {blocks} refill {refill}: {best:.2f} ms  {n/best/1e3:.1f} Mrays/s  (all: {', '.join('%.2f'%m for m in ms)})", flush=True)
+            print(f"   blocks/CU {blocks} refill {refill} chunk {chunk}: {best:.2f} ms  {n/best/1e3:.1f} Mrays/s  (all: {', '.join('%.2f'%m for m in ms)})", flush=True)
 d_rays.free(); d_hits.free()
 ctx.close()

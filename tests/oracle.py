@@ -50,6 +50,7 @@ def lib():
         L.po_trace.argtypes = [vp, vp, vp, i32, i32, i32]
         L.po_raysort.argtypes = [vp, vp]
         L.po_composite.argtypes = [vp, vp]
+        L.po_tonemap.argtypes = [vp, C.c_uint64, vp]
         L.po_render_frame.argtypes = [vp, vp, vp, i32, i32, i32, i32]
         L.po_intersect_bbox.argtypes = [vp, vp, vp]
         L.po_intersect_bbox.restype = i32
@@ -172,6 +173,14 @@ def raysort(frame, consts):
 
 def composite(frame, consts):
     lib().po_composite(frame.h, _p(consts))
+
+
+def tonemap(accumulation):
+    """(H, W, 4) float32 accumulation -> (H, W, 3) float32 display colour (composite.frag:18-26,57)."""
+    acc = np.ascontiguousarray(accumulation, dtype=np.float32)
+    out = np.zeros(acc.shape[:2] + (3,), dtype=np.float32)
+    lib().po_tonemap(_p(acc), acc.shape[0] * acc.shape[1], _p(out))
+    return out
 
 
 def render_frame(scene, frame, consts, subgroup0=0, ray_sort=True, mode=MODE_ZERO_NEXT_SLOT, flags=FLAG_REJECT_NAN):

@@ -203,3 +203,55 @@ def test_procedural_scenes_are_deterministic_and_clean():
         assert np.allclose(np.linalg.norm(a1["normal"], axis=1), 1, atol=1e-5)
     p, a, i = pt.scenes.courtyard(50000)
     assert abs(i.shape[0] - 50000) < 1500
+
+
+# ---- frame-dump interchange (PathTracer.cpp:180-202) ----------------------------------------------
+
+def test_frame_dump_pair_round_trip_and_python_zlib(tmp_path):
+    """The writer produces the reference's file pair: a zlib stream of W*H RGBA16F texels that python's zlib
+    inflates to the same bytes, and "W,H" in the .txt; the reader accepts a pair made without the library
+    (what a miniz-written dump looks like to it)."""
+    import zlib
+    rng = np.random.default_rng(5)
+    W, H = 37, 19
+    img = rng.standard_normal((H, W, 4)).astype(np.float16)
+    img[..., 3] = 1.0
+    pt.write_frame_dump(tmp_path, 7, img)
+    z = (tmp_path / "RayStackBuffer_7.bin.z").read_bytes()
+    assert zlib.decompress(z) == img.tobytes()
+    assert (tmp_path / "RayStackBuffer_7.bin.z.txt").read_text() == f"{W},{H}\n"
+    back = pt.read_frame_dump(tmp_path, 7)
+    assert back.shape == (H, W, 4) and back.tobytes() == img.tobytes()
+
+    # a pair written by another zlib implementation / level, CRLF in the size file
+    img2 = rng.standard_normal((H, W, 4)).astype(np.float16)
+    (tmp_path / "RayStackBuffer_8.bin.z").write_bytes(zlib.compress(img2.tobytes(), 1))
+    (tmp_path / "RayStackBuffer_8.bin.z.txt").write_text(f"{W},{H}\r\n")
+    assert pt.read_frame_dump(tmp_path, 8).tobytes() == img2.tobytes()
+
+
+def test_frame_dump_errors(tmp_path):
+    import zlib
+    with pytest.raises(pt.PtError, match="file I/O"):
+        pt.read_frame_dump(tmp_path, 1)
+    (tmp_path / "RayStackBuffer_2.bin.z.txt").write_text("4,4\n")
+    (tmp_path / "RayStackBuffer_2.bin.z").write_bytes(b"not a zlib stream")
+    with pytest.raises(pt.PtError, match="zlib"):
+        pt.read_frame_dump(tmp_path, 2)
+    (tmp_path / "RayStackBuffer_3.bin.z.txt").write_text("4,4\n")
+    (tmp_path / "RayStackBuffer_3.bin.z").write_bytes(zlib.compress(b"\0" * 64))      # 8 texels, size file says 16
+    with pytest.raises(pt.PtError, match="malformed"):
+        pt.read_frame_dump(tmp_path, 3)
+    (tmp_path / "RayStackBuffer_4.bin.z.txt").write_text("banana\n")
+    with pytest.raises(pt.PtError, match="malformed"):
+        pt.read_frame_dump(tmp_path, 4)
+    with pytest.raises(pt.PtError, match="file I/O"):
+        pt.write_frame_dump(tmp_path / "no_such_dir", 1, np.zeros((2, 2, 4), np.uint16))
+
+
+def test_write_ppm(tmp_path):
+    img = (np.arange(5 * 3 * 4) % 251).astype(np.uint8).reshape(3, 5, 4)
+    pt.write_ppm(tmp_path / "a.ppm", img)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n5 3\n255\n")
+    assert raw[len(b"P6\n5 3\n255\n"):] == img[..., :3].tobytes()

@@ -159,3 +159,19 @@ def test_frame_behaviour_switches(oracle_lib, monkey):
     ff = oracle.Frame(W, H, NR)
     oracle.render_frame(osc, ff, c1, ray_sort=True, mode=Z)
     assert np.array_equal(fe.accumulation, ff.accumulation)
+
+
+def test_tonemap_restatement(oracle_lib):
+    """composite.frag:18-26,57 against a float64 evaluation of the same formula; black for unsampled pixels."""
+    rng = np.random.default_rng(11)
+    acc = np.zeros((16, 32, 4), np.float32)
+    acc[..., :3] = rng.gamma(1.0, 20.0, (16, 32, 3))
+    acc[..., 3] = rng.integers(1, 64, (16, 32))
+    acc[0, 0] = 0.0                      # never sampled: 0/0
+    acc[0, 1, :3] = 1e8                  # saturates (2.51/2.43 > 1 clamps to 1)
+    out = oracle.tonemap(acc)
+    x = acc[..., :3].astype(np.float64) / np.maximum(acc[..., 3:4].astype(np.float64), 1e-300)
+    ref = np.clip((x * (2.51 * x + 0.03)) / (x * (2.43 * x + 0.59) + 0.14), 0, 1) ** (1 / 2.2)
+    ref[0, 0] = 0.0
+    assert np.abs(out - ref).max() < 2e-6
+    assert (out[0, 0] == 0).all() and np.allclose(out[0, 1], 1.0)

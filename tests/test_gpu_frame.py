@@ -23,7 +23,7 @@ def _setup(ctx, model, W, H, NR):
     lights, bn = pt.default_lights(), pt.load_blue_noise()
     helpers.upload(ctx, model, lights, bn)
     ctx.resize(W, H, NR)
-    for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0)):
+    for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0), (core.OPT_FRAMES_IN_FLIGHT, 2)):
         ctx.set_option(o, v)
     return helpers.oracle_scene(model, lights, bn), oracle.Frame(W, H, NR)
 
@@ -32,11 +32,23 @@ def _consts(model, W, H, NR, frame, cam):
     return pt.fill_constants(W, H, NR, model["indices"].shape[0], model["nodes"].shape[0], frame_index=frame, **cam)
 
 
-def _compare(ctx, fr, strict=True):
+def _compare(ctx, fr, strict=True, live_slots_only=False):
     slots, _ = ctx.readback_raystack()
     acc, cur = ctx.readback_accumulation(), ctx.readback_current()
     if strict:
-        assert np.array_equal(slots.view(np.uint8), fr.stack.view(np.uint8)), "ray stack differs"
+        if live_slots_only:
+            # slots the frame's paths reached; what lies beyond a path's end is left over from whichever earlier
+            # frame used this stack and never enters an image (the build zeroes prob of the slot after the end)
+            nr = fr.stack.shape[0] // (cur.shape[0] * cur.shape[1])
+            a, b = slots.reshape(-1, nr), fr.stack.reshape(-1, nr)
+            prob = b["prob"].view(np.float16).astype(np.float32)
+            reached = np.ones(prob.shape, bool)
+            reached[:, 1:] = np.cumprod(prob[:, :-1] > 0, axis=1).astype(bool)
+            assert np.array_equal(a["prob"][reached], b["prob"][reached])
+            full = reached & (prob > 0)
+            assert np.array_equal(a[full].view(np.uint8), b[full].view(np.uint8)), "ray stack differs in a live slot"
+        else:
+            assert np.array_equal(slots.view(np.uint8), fr.stack.view(np.uint8)), "ray stack differs"
         assert np.array_equal(cur, fr.current)
         assert np.array_equal(acc, fr.accumulation)
     else:
@@ -235,3 +247,59 @@ def test_allreduce_single_rank(gpu_ctx, monkey):
         assert np.array_equal(gpu_ctx.readback_accumulation(), before)
     finally:
         dist.destroy_process_group()
+
+
+def test_tonemap_and_frame_dump(gpu_ctx, oracle_lib, monkey, tmp_path):
+    """Display colour (composite.frag:18-26,57) against the oracle's restatement on the same accumulation, and the
+    frame-dump pair (PathTracer.cpp:180-202) holding exactly the RGBA16F current image.
+    Tolerance: the colour is fp32 with one powf (ocml on the GPU, libm in the oracle): 1e-5 relative to the
+    [0,1] range; the 8-bit image may differ by one step where the colour sits on a rounding boundary."""
+    import zlib
+    W, H, NR = 192, 104, 4
+    _setup(gpu_ctx, monkey, W, H, NR)
+    for frame in (1, 2, 3, 4):
+        gpu_ctx.set_constants(_consts(monkey, W, H, NR, frame, {}))
+        gpu_ctx.render_sample(frame)
+    acc, cur = gpu_ctx.readback_accumulation(), gpu_ctx.readback_current()
+    ref = oracle.tonemap(acc)
+    col = gpu_ctx.tonemap(want_float=True)
+    assert np.abs(col - ref).max() <= 1e-5
+    img = gpu_ctx.tonemap()
+    assert (img[..., 3] == 255).all()
+    step = np.abs(img[..., :3].astype(np.int32) - np.rint(ref * 255.0).astype(np.int32))
+    assert step.max() <= 1 and (step > 0).mean() <= 1e-3
+    assert img[..., :3].max() > 64          # the picture is not black
+
+    gpu_ctx.dump_current(tmp_path, 4)
+    assert zlib.decompress((tmp_path / "RayStackBuffer_4.bin.z").read_bytes()) == cur.tobytes()
+    assert (tmp_path / "RayStackBuffer_4.bin.z.txt").read_text() == f"{W},{H}\n"
+    assert np.array_equal(pt.read_frame_dump(tmp_path, 4), cur)
+    pt.write_ppm(tmp_path / "monkey.ppm", img)
+    assert (tmp_path / "monkey.ppm").stat().st_size == len(f"P6\n{W} {H}\n255\n") + W * H * 3
+
+
+@pytest.mark.parametrize("in_flight", [1, 2, 3, 4])
+@pytest.mark.parametrize("reseed", [0, 1])
+def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_flight, reseed):
+    """pt_render_samples with several frames in flight leaves the ray stack, the current image and the accumulation of
+    the same frames rendered one after the other (the oracle does exactly that), and a pt_render_sample that follows
+    continues the RNG chain from the batch's last frame."""
+    W, H, NR, NF = 160, 88, 4, 7
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_RESEED, reseed)
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, in_flight)
+    mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS | (oracle.MODE_RESEED_EVERY_FRAME if reseed else 0)
+    c = _consts(monkey, W, H, NR, 1, {})
+    gpu_ctx.set_constants(c)
+    rc = gpu_ctx.render_samples(1, NF, want_ray_counts=True)
+    for frame in range(1, NF + 1):
+        c["frameIndex"] = frame
+        oracle.render_frame(osc, fr, c, mode=mode)
+    _compare(gpu_ctx, fr, live_slots_only=in_flight > 1)
+    counts = fr.ray_counts()
+    assert int(rc[0::2][:NR].sum()) == int(counts[0]) and int(rc[1::2][:NR].sum()) == int(counts[1])
+    gpu_ctx.render_sample(NF + 1)
+    c["frameIndex"] = NF + 1
+    oracle.render_frame(osc, fr, c, mode=mode)
+    _compare(gpu_ctx, fr, live_slots_only=in_flight > 1)
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
