@@ -226,7 +226,7 @@ def cpu_baseline(pos, aux, ridx, nodes, d_rays, budget_s):
 
 def path_tracer_spp(ctx, threads):
     """Context number: samples per pixel per second of the wavefront path tracer at 1080p, 8 bounces with
-    next-event estimation, on the sponza stand-in (BASELINE configs[2])."""
+    next-event estimation, on the sponza stand-in (BASELINE configs[2]); frames in flight at the library default."""
     import pathtracer_amd as pt
     pos, aux, idx = pt.scenes.sponza_like()
     nodes, ridx, _ = pt.build_bvh(pos, idx, threads)
@@ -236,13 +236,11 @@ def path_tracer_spp(ctx, threads):
     c = pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], orbit_height=0.6, orbit_radius=1.6, orbit_angle=0.4,
                           focus_center=(0.0, 0.5, 0.0))
     ctx.set_constants(c)
-    for f in range(1, 4):
-        ctx.render_sample(f)
+    ctx.render_samples(1, 3)
     ctx.synchronize()
-    nf = 20
+    nf = 30
     t = time.perf_counter()
-    for f in range(4, 4 + nf):
-        ctx.render_sample(f)
+    ctx.render_samples(4, nf)
     ctx.synchronize()
     dt = time.perf_counter() - t
     rc = ctx.render_sample(4 + nf, want_ray_counts=True)

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                overflow load it would become a flat load, which goes through the vector-memory path */
             const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
             uint32_t ref = sRef[wave][e][lane]; uint16_t tb = sTmin[wave][e][lane];
+            asm volatile("" : "+v"(ref));       /* keeps the two sources apart: see above */
             if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; tb = (uint16_t)o.y; }
             if (r.max_t > (float)hfrombits(tb)) { cur = ref; needPop = false; }
         }
