@@ -226,6 +226,11 @@ def courtyard(num_triangles, seed=7, extent=2.0):
     return m.finish()
 
 
+# A camera for the courtyard stand-ins (keyword arguments of fill_constants): in a corner above the tree crowns, looking
+# down into the yard, so that the picture holds walls, arcade, furniture and foliage instead of the inside of a crown.
+COURTYARD_CAMERA = dict(orbit_angle=2.4, orbit_radius=2.6, orbit_height=1.4, focus_center=(0.0, 0.2, 0.0))
+
+
 def sponza_like(num_triangles=262_144, seed=11):
     """Stand-in for sponza.ply (a 16.8 MB PLY whose geometry is not in the reference checkout)."""
     return courtyard(num_triangles, seed=seed, extent=2.0)

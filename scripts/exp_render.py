@@ -21,10 +21,10 @@ if args.scene == "bunny":
     cam = dict(orbit_angle=-np.pi / 2, orbit_height=0.75, focus_center=(0.0, 0.75, 0.0))
 elif args.scene == "sanmiguel":
     pos, aux, idx = pt.scenes.san_miguel_like()
-    cam = dict(orbit_height=0.6, orbit_radius=1.6, orbit_angle=0.4, focus_center=(0.0, 0.5, 0.0))
+    cam = dict(pt.scenes.COURTYARD_CAMERA)
 else:
     pos, aux, idx = pt.scenes.sponza_like()
-    cam = dict(orbit_height=0.6, orbit_radius=1.6, orbit_angle=0.4, focus_center=(0.0, 0.5, 0.0))
+    cam = dict(pt.scenes.COURTYARD_CAMERA)
 nodes, ridx, _ = pt.build_bvh(pos, idx, 16)
 ctx = pt.PathTracer(0)
 ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
