@@ -59,9 +59,15 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    # PT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    device = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     import pathtracer_amd as pt
     from pathtracer_amd import core
@@ -72,7 +78,7 @@ def main():
     t1 = time.time()
     nodes, ridx, depth = pt.build_bvh(pos, idx, threads)
     t2 = time.time()
-    ctx = pt.PathTracer(local_rank)
+    ctx = pt.PathTracer(device)
     ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
     if args.traversal >= 0:
         ctx.set_option(core.OPT_TRAVERSAL, args.traversal)
@@ -111,7 +117,7 @@ def main():
     elapsed = time.perf_counter() - tstart
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -161,3 +161,65 @@ def test_generated_rays_and_device_path(gpu_ctx, oracle_lib, bunny):
     ref = osc.trace(rays)
     assert np.array_equal(hits, ref)
     assert gpu_ctx.last_kernel_ms() > 0
+
+
+def test_full_size_microbench_properties(gpu_ctx):
+    """The headline configuration (5.8 M-triangle stand-in, 2^26 incoherent rays) is beyond what the CPU oracle
+    finishes in seconds, so it is checked through properties that hold at any size:
+      * the reference-order and the near-child-first traversal agree on >= 99.99 % of rays, and where they name
+        the same triangle t is bit-identical (same arithmetic on the same record);
+      * an any-hit query reports a hit exactly where the closest-hit query finds one (same interval);
+      * the reported t is the fp64 Moeller-Trumbore distance of the reported triangle (to fp32 accuracy), lies in
+        [min_t, max_t], and the barycentric point is inside the triangle;
+      * a second launch returns the same bytes."""
+    pos, aux, idx = pt.scenes.san_miguel_like()
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 16)
+    ctx = gpu_ctx
+    ctx.upload_scene(pos, aux, ridx, nodes)
+    n = 1 << 26
+    d_rays, d_a, d_b = ctx.alloc(n * 32), ctx.alloc(n * 16), ctx.alloc(n * 16)
+    try:
+        ctx.generate_rays(d_rays, n)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        ctx.trace_rays_device(d_rays, n, d_a)
+        near = d_a.to_host(pt.HIT_DT)
+        ctx.trace_rays_device(d_rays, n, d_b)
+        assert np.array_equal(d_b.to_host(pt.HIT_DT).view(np.uint8), near.view(np.uint8)), "not deterministic"
+        ctx.trace_rays_device(d_rays, n, d_b, any_hit=True)
+        anyh = d_b.to_host(pt.HIT_DT)
+        assert np.array_equal(anyh["i1"] >= 0, near["i1"] >= 0), "any-hit verdict differs from closest-hit"
+        del anyh
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        ctx.trace_rays_device(d_rays, n, d_b)
+        order = d_b.to_host(pt.HIT_DT)
+        same = (near["i1"] == order["i1"]) & (near["i2"] == order["i2"]) & (near["i3"] == order["i3"])
+        assert (~same).mean() <= 1e-4, f"{(~same).mean():.2e} of rays differ between the two visit orders"
+        assert np.array_equal(near["t"][same].view(np.uint32), order["t"][same].view(np.uint32))
+        diff = ~same & (near["i1"] >= 0) & (order["i1"] >= 0)
+        extent = float((pos[:, :3].max(axis=0) - pos[:, :3].min(axis=0)).max())
+        assert np.abs(near["t"][diff] - order["t"][diff]).max(initial=0.0) <= extent / 512
+        del order
+
+        # geometry of the reported hits, on every 16th ray
+        rays = d_rays.to_host(pt.RAY_DT)[::16]
+        h = near[::16]
+        m = h["i1"] >= 0
+        assert 0.5 < m.mean() < 0.95
+        o, d = rays["o"][m].astype(np.float64), rays["d"][m].astype(np.float64)
+        p1, p2, p3 = (pos[h[k][m], :3].astype(np.float64) for k in ("i1", "i2", "i3"))
+        e1, e2, s = p2 - p1, p3 - p1, o - p1
+        s1, s2 = np.cross(d, e2), np.cross(s, e1)
+        det = (s1 * e1).sum(1)
+        t, a, b = (s2 * e2).sum(1) / det, (s1 * s).sum(1) / det, (s2 * d).sum(1) / det
+        assert np.abs(t - h["t"][m]).max() <= 1e-4 * max(extent, 1.0)      # fp32 arithmetic on a grazing triangle
+        assert (h["t"][m] >= rays["min_t"][m]).all() and (h["t"][m] <= rays["max_t"][m]).all()
+        # inside the triangle up to the fp32 rounding of the kernel's own alpha and beta, which grows as the ray
+        # approaches the triangle's plane (|det| small against the products it is the difference of)
+        nrm = np.linalg.norm
+        tol = 64 * 2.0 ** -24 * (nrm(s1, axis=1) * nrm(s, axis=1) + nrm(s2, axis=1) * nrm(d, axis=1)) / np.abs(det) + 1e-6
+        assert (a >= -tol).all() and (b >= -tol).all() and (1 - a - b >= -2 * tol).all()
+        assert (a < -1e-3).mean() <= 1e-4
+        assert (near["t"][near["i1"] < 0] == rays["max_t"][0]).all()        # a miss returns the interval's end
+    finally:
+        d_rays.free(); d_a.free(); d_b.free()
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
