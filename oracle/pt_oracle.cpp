@@ -250,6 +250,7 @@ struct PoScene {
     std::vector<PtBVHNode> nodes;
     std::vector<PtLight> lights;
     std::vector<uint16_t> blueNoise;
+    std::vector<uint8_t> oddInterior;   /* analysis only, see PO_FLAG_SKIP_ODD_INTERIOR */
 };
 
 struct Ray {                        /* structures.glsl:13-21 */
@@ -260,7 +261,13 @@ struct Intersection { H3 bary; int32_t i1, i2, i3; };   /* structures.glsl:29-33
 struct TraceCounters { uint64_t boxTests = 0, triTests = 0; };
 
 /* flags shared by the entry points below */
-enum { PO_FLAG_REJECT_NAN = 1 };    /* positive-form acceptance test: a NaN t/alpha/beta rejects (see intersect) */
+enum {
+    PO_FLAG_REJECT_NAN = 1,         /* positive-form acceptance test: a NaN t/alpha/beta rejects (see intersect) */
+    PO_FLAG_SKIP_ODD_INTERIOR = 2   /* ANALYSIS ONLY, not the reference's walk: interior nodes at odd depth pass their box
+                                       test unconditionally, which is what a four-wide node that stores only its
+                                       grandchildren's boxes would do.  Measures how often the reference's own (not
+                                       conservative) fp16 test of such a node changes a result. */
+};
 
 static inline H3 rcp_dir(F3 d) { return { f2h(1.0f / d.x), f2h(1.0f / d.y), f2h(1.0f / d.z) }; }
 
@@ -377,10 +384,11 @@ static bool traceRayFast(const PoScene& sc, Ray& r, Intersection& isect, bool st
     bool hit = false;
     uint32_t index = 0, hitIndex = 0;
     uint64_t nb = 0, nt = 0;
+    const uint8_t* skipOdd = ((flags & PO_FLAG_SKIP_ODD_INTERIOR) && !sc.oddInterior.empty()) ? sc.oddInterior.data() : nullptr;
     while (index < numBVHNodes) {
         const PtBVHNode& nd = nodes[index];
         nb++;
-        if (intersectBBox(r, nd.a, nd.b)) {
+        if ((skipOdd && skipOdd[index]) || intersectBBox(r, nd.a, nd.b)) {
             int32_t right = nd.right;
             if (right <= 0 && (r.origBvhId == 0 || r.origBvhId != index)) {
                 uint32_t tri = (uint32_t)(-right) / 3;
@@ -413,6 +421,15 @@ PO_API PoScene* po_scene_create(const float* pos4, uint32_t V, const PtVertexAux
     s->nodes.assign(nodes, nodes + N);
     if (lights) s->lights.assign(lights, lights + L);
     if (blueNoise) s->blueNoise.assign(blueNoise, blueNoise + 65536);
+    /* depth parity of interior nodes (pre-order array: left child = i + 1, right child = nodes[i].right) */
+    s->oddInterior.assign(N, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> st; st.push_back({ 0u, 0u });
+    while (!st.empty()) {
+        auto [i, d] = st.back(); st.pop_back();
+        if (i >= N || nodes[i].right <= 0) continue;
+        s->oddInterior[i] = (uint8_t)(d & 1u);
+        st.push_back({ (uint32_t)nodes[i].right, d + 1 }); st.push_back({ i + 1, d + 1 });
+    }
     return s;
 }
 PO_API void po_scene_destroy(PoScene* s) { delete s; }

@@ -21,6 +21,7 @@ CONST_DT = np.dtype([("viewMtx", "<f4", 16), ("projMtx", "<f4", 16), ("viewInvMt
 assert NODE_DT.itemsize == 32 and SLOT_DT.itemsize == 48 and CONST_DT.itemsize == 320 and AUX_DT.itemsize == 16
 
 FLAG_REJECT_NAN = 1
+FLAG_SKIP_ODD_INTERIOR = 2      # analysis only (scripts/exp_wide_nodes.py)
 MODE_ZERO_NEXT_SLOT, MODE_RESEED_EVERY_FRAME, MODE_KILL_ON_MISS = 1, 2, 4
 
 _lib = None

@@ -303,3 +303,22 @@ def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_fligh
     oracle.render_frame(osc, fr, c, mode=mode)
     _compare(gpu_ctx, fr, live_slots_only=in_flight > 1)
     gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
+
+
+def test_cornell_box_512_four_bounces(gpu_ctx, oracle_lib):
+    """The plumbing configuration: Cornell box (stand-in geometry, 34 triangles) at 512 x 512 with 4 bounces from the
+    reference's default camera; every buffer equals the oracle's after two frames."""
+    pos, aux, idx = pt.scenes.cornell_box()
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 1)
+    model = dict(positions=pos, aux=aux, indices=ridx, nodes=nodes)
+    W, H, NR = 512, 512, 4
+    osc, fr = _setup(gpu_ctx, model, W, H, NR)
+    cam = dict(focus_center=(0.0, 1.0, 0.0), orbit_height=1.0, orbit_radius=3.4, orbit_angle=0.0)
+    for frame in (1, 2):
+        c = _consts(model, W, H, NR, frame, cam)
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_sample(frame)
+        oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        _compare(gpu_ctx, fr)
+    acc = gpu_ctx.readback_accumulation()
+    assert (acc[..., :3].sum(axis=2) > 0).mean() > 0.3          # the box is in view and lit
