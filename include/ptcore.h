@@ -102,13 +102,33 @@ typedef struct PtHit {
  * Child reference: bit 31 set = leaf, low 31 bits = index into the triangle records;
  * clear = index into the PtNode2 array. */
 typedef struct PtNode2 {
-    float    cL[3];              /* centre of the left child's box */
-    float    cR[3];              /* centre of the right child's box */
-    uint16_t h[6][2];            /* f16(a-c).xyz then f16(b-c).xyz, each stored as the pair (left child, right child) */
+    float    c[3][2];            /* box centres x, y, z, each stored as the pair (left child, right child) */
+    uint16_t h[6][2];            /* f16(a-c).xyz then f16(b-c).xyz, each as the pair (left child, right child): one
+                                    packed instruction then works on both children's boxes */
     uint32_t left, right;
     uint32_t refIndex;           /* index of this interior node in the reference array */
     uint32_t _pad;
 } PtNode2;
+
+/* The same two boxes in 48 B (PT_OPT_RECORD_LAYOUT = 1), three 16 B accesses per lane instead of four.
+ * f16(b-c) is not stored: it is non-negative and its magnitude bits differ from those of
+ * f16(a-c) by a few units at most (c is the rounded midpoint), so it is rebuilt exactly from hA and a 5-bit
+ * difference.  pt_flatten_bvh_compact checks every box and refuses a tree with a box that does not fit. */
+typedef struct PtNode2c {
+    float    c[3][2];            /* as PtNode2 */
+    uint16_t hA[3][2];           /* f16(a-c).xyz as (left child, right child) pairs */
+    uint32_t left, right;        /* as PtNode2 */
+    uint32_t delta;              /* axis k: left child in bits 5k..5k+4, right child in bits 16+5k..16+5k+4, each
+                                    d + 15 with  bits(f16(b-c)) = (bits(f16(a-c)) & 0x7FFF) + d,  -15 <= d <= 15 */
+} PtNode2c;
+
+/* Flattened leaf in 48 B: PtTri without its last quarter.  The leaf's reference node index, needed only when a walk
+ * runs off the end of the reference array (intersections.glsl:109-113), comes from a separate table. */
+typedef struct PtTriC {
+    float    p1[3];  int32_t i1;
+    float    e1[3];  int32_t i2;
+    float    e2[3];  int32_t i3;
+} PtTriC;
 
 /* Flattened leaf, 64 B: the triangle the reference reaches through two dependent texel
  * fetches (intersections.glsl:86-94), stored inline.  e1 = p2-p1 and e2 = p3-p1 are the
@@ -154,6 +174,13 @@ PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
 
 /* Replaces the constants block filled at PathTracer.cpp:731-750 (glm::lookAt, glm::perspective
  * with the y flip, glm::inverse) for the orbit camera of PathTracer.cpp:109-112. */
+/* The flattening pass with 48 B records.  leaf_ref[t] receives the reference node index of the leaf that holds
+ * triangle t.  Returns 1 (and says so in err) if some box cannot be encoded; the caller then uses pt_flatten_bvh. */
+PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes,
+                                  const float* positions, const uint32_t* indices, uint32_t num_triangles,
+                                  PtNode2c* nodes2, PtTriC* tris, uint32_t* leaf_ref, float* root_box,
+                                  uint32_t* max_stack, char* err, size_t err_len);
+
 PT_API void pt_fill_constants(PtShaderConstants* c, uint32_t width, uint32_t height,
                               const float focus_center[3], float orbit_height, float orbit_radius,
                               float orbit_angle, uint32_t num_lights, uint32_t num_triangles,
@@ -184,6 +211,10 @@ enum {
     PT_OPT_REFILL_MIN     = 5,   /* a wavefront refills its idle lanes once this many of its 64 are idle */
     PT_OPT_CLAIM_CHUNK    = 6,   /* ray ids a wavefront takes from the global counter at a time: 0 = chosen from the
                                     ray count (64..128), else 64..1024 in steps of 64 */
+    PT_OPT_RECORD_LAYOUT  = 8,   /* read by pt_scene_upload: 0 (default) = 64 B records; 1 = 48 B records when every box
+                                    can be encoded (pt_flatten_bvh_compact), else 64 B.  Results do not depend on it;
+                                    48 B records save a quarter of the record memory and measure about 5 % slower
+                                    (one record in four then lies across two 128 B lines) */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..4 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and pair of streams; results do not depend on it */
 };
@@ -322,5 +353,6 @@ PT_SA(sizeof(PtBVHNode) == 32 && offsetof(PtBVHNode, next) == 12 && offsetof(PtB
       offsetof(PtBVHNode, right) == 28, "BVHNode is 32 B");
 PT_SA(sizeof(PtRay) == 32 && sizeof(PtHit) == 16, "microbench ray 32 B, hit 16 B");
 PT_SA(sizeof(PtNode2) == 64 && sizeof(PtTri) == 64, "flattened records are 64 B");
+PT_SA(sizeof(PtNode2c) == 48 && sizeof(PtTriC) == 48, "compact flattened records are 48 B");
 
 #endif /* PTCORE_H */

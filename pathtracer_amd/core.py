@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 NODE_DT = np.dtype([("a", "<f4", 3), ("next", "<i4"), ("b", "<f4", 3), ("right", "<i4")])
-NODE2_DT = np.dtype([("cL", "<f4", 3), ("cR", "<f4", 3), ("h", "<u2", (6, 2)), ("left", "<u4"), ("right", "<u4"),
+NODE2_DT = np.dtype([("c", "<f4", (3, 2)), ("h", "<u2", (6, 2)), ("left", "<u4"), ("right", "<u4"),
                      ("refIndex", "<u4"), ("_pad", "<u4")])
 TRI_DT = np.dtype([("p1", "<f4", 3), ("i1", "<i4"), ("e1", "<f4", 3), ("i2", "<i4"), ("e2", "<f4", 3), ("i3", "<i4"),
                    ("refLeaf", "<u4"), ("flags", "<u4"), ("_pad", "<u4", 2)])
@@ -27,11 +27,15 @@ CONST_DT = np.dtype([("viewMtx", "<f4", 16), ("projMtx", "<f4", 16), ("viewInvMt
                      ("viewportSize", "<f4", 2), ("viewportBase", "<f4", 2), ("numLights", "<u4"), ("numTriangles", "<u4"),
                      ("frameIndex", "<u4"), ("numRays", "<u4"), ("numBVHNodes", "<u4"), ("_pad0", "<u4", 3),
                      ("ambientRadiance", "<f4", 3), ("_pad1", "<u4")])
+NODE2C_DT = np.dtype([("c", "<f4", (3, 2)), ("hA", "<u2", (3, 2)), ("left", "<u4"), ("right", "<u4"), ("delta", "<u4")])
+TRIC_DT = np.dtype([("p1", "<f4", 3), ("i1", "<i4"), ("e1", "<f4", 3), ("i2", "<i4"), ("e2", "<f4", 3), ("i3", "<i4")])
 assert (NODE_DT.itemsize, NODE2_DT.itemsize, TRI_DT.itemsize, RAY_DT.itemsize, HIT_DT.itemsize) == (32, 64, 64, 32, 16)
+assert (NODE2C_DT.itemsize, TRIC_DT.itemsize) == (48, 48)
 assert (LIGHT_DT.itemsize, AUX_DT.itemsize, SLOT_DT.itemsize, CONST_DT.itemsize) == (32, 16, 48, 320)
 
 OPT_TRAVERSAL, OPT_STALE_SLOTS, OPT_RESEED, OPT_PERSIST_BLOCKS, OPT_REFILL_MIN, OPT_CLAIM_CHUNK = 1, 2, 3, 4, 5, 6
 OPT_FRAMES_IN_FLIGHT = 7
+OPT_RECORD_LAYOUT = 8           # 0 = 64 B records (default), 1 = 48 B records when every box can be encoded
 TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED = 0, 1, 2
 
 
@@ -68,6 +72,7 @@ def _load():
         "pt_ply_load": (i32, [cp, pu32, pu32, vp, vp, vp, cp, sz]),
         "pt_build_bvh": (i32, [vp, u32, vp, u32, vp, pu32, i32, cp, sz]),
         "pt_flatten_bvh": (i32, [vp, u32, vp, vp, u32, vp, vp, vp, pu32, cp, sz]),
+        "pt_flatten_bvh_compact": (i32, [vp, u32, vp, vp, u32, vp, vp, vp, vp, pu32, cp, sz]),
         "pt_fill_constants": (None, [vp, u32, u32, vp, C.c_float, C.c_float, C.c_float, u32, u32, u32, u32, u32, vp]),
         "pt_ctx_create": (i32, [i32, C.POINTER(vp)]),
         "pt_ctx_destroy": (None, [vp]),
@@ -171,6 +176,28 @@ def flatten_bvh(nodes, positions, indices):
     if L.pt_flatten_bvh(_p(nodes), nodes.shape[0], _p(pos), _p(idx), T, _p(n2), _p(tr), _p(rb), C.byref(ms), err, 256) != 0:
         raise PtError(err.value.decode())
     return n2[:max(T - 1, 0)], tr, rb, ms.value
+
+
+def flatten_bvh_compact(nodes, positions, indices):
+    """The flattening pass with 48 B records.  Returns (nodes2 [T-1] NODE2C_DT, tris [T] TRIC_DT, leaf_ref [T] u32,
+    root_box [6], max_stack), or None if some box does not fit the encoding."""
+    L = _load()
+    nodes = np.ascontiguousarray(nodes)
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    T = idx.shape[0]
+    n2 = np.zeros(max(T - 1, 1), dtype=NODE2C_DT)
+    tr = np.zeros(T, dtype=TRIC_DT)
+    lr = np.zeros(T, dtype=np.uint32)
+    rb = np.zeros(6, dtype=np.float32)
+    ms = C.c_uint32(0)
+    err = C.create_string_buffer(256)
+    rc = L.pt_flatten_bvh_compact(_p(nodes), nodes.shape[0], _p(pos), _p(idx), T, _p(n2), _p(tr), _p(lr), _p(rb), C.byref(ms), err, 256)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise PtError(err.value.decode())
+    return n2[:max(T - 1, 0)], tr, lr, rb, ms.value
 
 
 def fill_constants(width, height, num_rays, num_triangles, num_bvh_nodes, frame_index=1, focus_center=(0.0, 0.0, 0.0),

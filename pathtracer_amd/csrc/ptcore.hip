@@ -83,6 +83,7 @@ struct PtContext {
     float4* dPositions = nullptr; PtVertexAux* dAux = nullptr; uint32_t* dIndices = nullptr; PtBVHNode* dNodes = nullptr;
     PtLight* dLights = nullptr; uint16_t* dBlueNoise = nullptr;
     uint4* dRecords = nullptr; uint2* dOverflow = nullptr; uint32_t leafBase = 0, recordBytes = 0;
+    bool compact = false; uint32_t* dLeafRef = nullptr; uint32_t lastLeaf = 0;      /* 48 B records */
     uint32_t V = 0, T = 0, N = 0, L = 0, maxStack = 0, overflowEntries = 0;
     uint64_t overflowLanes = 0; int overflowAreas = 0;
     float rootBox[6] = {0}; float rootC[3] = {0}; uint16_t rootH[6] = {0};
@@ -98,7 +99,7 @@ struct PtContext {
     uint32_t* dFetch = nullptr; unsigned long long* dStats = nullptr;      /* pt_trace_rays: id counter, visit statistics */
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0;
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
 
@@ -118,7 +119,7 @@ template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; }
 void free_scene(PtContext* c)
 {
     dfree(c->dPositions); dfree(c->dAux); dfree(c->dIndices); dfree(c->dNodes); dfree(c->dLights); dfree(c->dBlueNoise);
-    dfree(c->dRecords); dfree(c->dOverflow);
+    dfree(c->dRecords); dfree(c->dOverflow); dfree(c->dLeafRef);
     c->V = c->T = c->N = c->L = 0;
 }
 void free_pipe_buffers(FramePipe& p)
@@ -159,6 +160,7 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     memset(&a, 0, sizeof(a));
     a.nodes = c->dNodes; a.numNodes = c->N; a.indices = c->dIndices; a.positions = c->dPositions;
     a.records = c->dRecords; a.recordBytes = c->recordBytes; a.leafBase = c->leafBase; a.tris = c->dRecords + c->leafBase / 16;
+    a.leafRef = c->dLeafRef; a.lastLeaf = c->lastLeaf;
     for (int k = 0; k < 3; k++) a.rootC[k] = c->rootC[k];
     for (int k = 0; k < 6; k++) a.rootH[k] = c->rootH[k];
     a.rootRef = (c->T == 1) ? PT_LEAF_BIT : 0u;
@@ -179,12 +181,20 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
+    } else if (ctx->compact) {
+        if (trav == 1) {
+            if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, false, true, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, false, false, true>), grid, block, 0, stream, a);
+        } else {
+            if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, true, true, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, true, false, true>), grid, block, 0, stream, a);
+        }
     } else if (trav == 1) {
-        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, false, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, false, false>), grid, block, 0, stream, a);
+        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, false, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, false, false, false>), grid, block, 0, stream, a);
     } else {
-        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, true, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, true, false>), grid, block, 0, stream, a);
+        if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, true, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, true, false, false>), grid, block, 0, stream, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -337,6 +347,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_PERSIST_BLOCKS: if (value < 1 || value > 8) return ctx->fail(-1, "PT_OPT_PERSIST_BLOCKS must be 1..8"); ctx->optBlocksPerCU = value; return 0;
         case PT_OPT_REFILL_MIN: if (value < 1 || value > 64) return ctx->fail(-1, "PT_OPT_REFILL_MIN must be 1..64"); ctx->optRefillMin = value; return 0;
         case PT_OPT_CLAIM_CHUNK: if (value < 0 || value > 1024 || value % 64) return ctx->fail(-1, "PT_OPT_CLAIM_CHUNK must be 0 or a multiple of 64 up to 1024"); ctx->optClaimChunk = value; return 0;
+        case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0 or 1"); ctx->optRecordLayout = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..4"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
@@ -352,6 +363,7 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_REFILL_MIN: *value = ctx->optRefillMin; return 0;
         case PT_OPT_CLAIM_CHUNK: *value = ctx->optClaimChunk; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: *value = ctx->optFramesInFlight; return 0;
+        case PT_OPT_RECORD_LAYOUT: *value = ctx->optRecordLayout; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
 }
@@ -371,13 +383,27 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
     if (int rc = sync_all(ctx)) return rc;
     free_scene(ctx);
 
-    std::vector<PtNode2> n2(T > 1 ? T - 1 : 1);
-    std::vector<PtTri> tr(T);
+    /* traversal records: 64 B each, or 48 B each when the option asks for it and every box fits that encoding; interior
+       and leaf records share one buffer so that one buffer descriptor serves every fetch */
     char ebuf[256] = {0};
     uint32_t maxStack = 0;
-    if (pt_flatten_bvh(nodes, N, positions, indices, T, n2.data(), tr.data(), ctx->rootBox, &maxStack, ebuf, sizeof(ebuf)) != 0)
-        return ctx->fail(-1, ebuf);
+    std::vector<PtNode2c> c2; std::vector<PtTriC> ct; std::vector<uint32_t> leafRef;
+    std::vector<PtNode2> n2; std::vector<PtTri> tr;
+    ctx->compact = false;
+    if (ctx->optRecordLayout == 1) {
+        c2.resize(T > 1 ? T - 1 : 1); ct.resize(T); leafRef.resize(T);
+        int rc = pt_flatten_bvh_compact(nodes, N, positions, indices, T, c2.data(), ct.data(), leafRef.data(), ctx->rootBox, &maxStack, ebuf, sizeof(ebuf));
+        if (rc < 0) return ctx->fail(-1, ebuf);
+        ctx->compact = rc == 0;
+    }
+    if (!ctx->compact) {
+        c2.clear(); ct.clear(); leafRef.clear();
+        n2.resize(T > 1 ? T - 1 : 1); tr.resize(T);
+        if (pt_flatten_bvh(nodes, N, positions, indices, T, n2.data(), tr.data(), ctx->rootBox, &maxStack, ebuf, sizeof(ebuf)) != 0)
+            return ctx->fail(-1, ebuf);
+    }
     ctx->maxStack = maxStack;
+    ctx->lastLeaf = (uint32_t)(-nodes[N - 1].right) / 3u;          /* the last node of a pre-order array is a leaf */
     for (int k = 0; k < 3; k++) {      /* root box digest, as for every other box (intersections.glsl:3-5) */
         ctx->rootC[k] = (ctx->rootBox[k] + ctx->rootBox[3 + k]) * 0.5f;
         _Float16 ha = (_Float16)(ctx->rootBox[k] - ctx->rootC[k]), hb = (_Float16)(ctx->rootBox[3 + k] - ctx->rootC[k]);
@@ -387,16 +413,30 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
     HIPCHK(hipMalloc((void**)&ctx->dPositions, (size_t)V * 16));
     HIPCHK(hipMalloc((void**)&ctx->dIndices, (size_t)T * 12));
     HIPCHK(hipMalloc((void**)&ctx->dNodes, (size_t)N * sizeof(PtBVHNode)));
-    /* interior records and leaf records share one buffer so that one buffer descriptor serves every fetch */
-    const size_t interiorBytes = (size_t)(T - 1) * sizeof(PtNode2), recBytes = interiorBytes + (size_t)T * sizeof(PtTri);
-    if (recBytes >= 0xFFFFFFFFull) return ctx->fail(-1, "pt_scene_upload: more than 2^32 bytes of traversal records (about 33 M triangles)");
+    const size_t recSize = ctx->compact ? (size_t)PT_COMPACT_STRIDE : sizeof(PtNode2);
+    const size_t interiorBytes = (size_t)(T - 1) * recSize, recBytes = interiorBytes + (size_t)T * recSize;
+    if (recBytes >= 0xFFFFFFFFull) return ctx->fail(-1, "pt_scene_upload: more than 2^32 bytes of traversal records");
     HIPCHK(hipMalloc((void**)&ctx->dRecords, recBytes));
     ctx->leafBase = (uint32_t)interiorBytes; ctx->recordBytes = (uint32_t)recBytes;
     HIPCHK(hipMemcpy(ctx->dPositions, positions, (size_t)V * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->dIndices, indices, (size_t)T * 12, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->dNodes, nodes, (size_t)N * sizeof(PtBVHNode), hipMemcpyHostToDevice));
-    if (T > 1) HIPCHK(hipMemcpy(ctx->dRecords, n2.data(), interiorBytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy((char*)ctx->dRecords + interiorBytes, tr.data(), (size_t)T * sizeof(PtTri), hipMemcpyHostToDevice));
+    if (ctx->compact && recSize == sizeof(PtNode2c)) {
+        if (T > 1) HIPCHK(hipMemcpy(ctx->dRecords, c2.data(), interiorBytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((char*)ctx->dRecords + interiorBytes, ct.data(), (size_t)T * recSize, hipMemcpyHostToDevice));
+    } else if (ctx->compact) {      /* records spaced wider than their 48 B: staged with the padding */
+        std::vector<unsigned char> staged(recBytes, 0);
+        for (size_t i = 0; i + 1 < (size_t)T; i++) memcpy(staged.data() + i * recSize, &c2[i], sizeof(PtNode2c));
+        for (size_t i = 0; i < (size_t)T; i++) memcpy(staged.data() + interiorBytes + i * recSize, &ct[i], sizeof(PtTriC));
+        HIPCHK(hipMemcpy(ctx->dRecords, staged.data(), recBytes, hipMemcpyHostToDevice));
+    } else {
+        if (T > 1) HIPCHK(hipMemcpy(ctx->dRecords, n2.data(), interiorBytes, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy((char*)ctx->dRecords + interiorBytes, tr.data(), (size_t)T * recSize, hipMemcpyHostToDevice));
+    }
+    if (ctx->compact) {
+        HIPCHK(hipMalloc((void**)&ctx->dLeafRef, (size_t)T * 4));
+        HIPCHK(hipMemcpy(ctx->dLeafRef, leafRef.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    }
     if (aux) {
         HIPCHK(hipMalloc((void**)&ctx->dAux, (size_t)V * 16));
         HIPCHK(hipMemcpy(ctx->dAux, aux, (size_t)V * 16, hipMemcpyHostToDevice));

@@ -64,9 +64,10 @@ extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
         if (n.right > 0) {
             PtNode2& o = nodes2[rank[i]];
             memset(&o, 0, sizeof(o));
-            uint16_t hl[6], hr[6];
-            digest_box(nodes[i + 1], o.cL, hl);
-            digest_box(nodes[n.right], o.cR, hr);
+            uint16_t hl[6], hr[6]; float cl[3], cr[3];
+            digest_box(nodes[i + 1], cl, hl);
+            digest_box(nodes[n.right], cr, hr);
+            for (int k = 0; k < 3; k++) { o.c[k][0] = cl[k]; o.c[k][1] = cr[k]; }
             for (int k = 0; k < 6; k++) { o.h[k][0] = hl[k]; o.h[k][1] = hr[k]; }
             o.left = child_ref(i + 1);
             o.right = child_ref((uint32_t)n.right);
@@ -96,6 +97,86 @@ extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
         }
         *max_stack = deepest;
     }
+    return 0;
+}
+
+/* Shared by both flattening passes: rank of every reference node among the interior nodes (pre-order) or, for a leaf,
+ * its triangle index; returns 0 or an error code with a message. */
+static int rank_nodes(const PtBVHNode* nodes, uint32_t num_nodes, uint32_t num_triangles, std::vector<uint32_t>& rank, char* err, size_t err_len)
+{
+    if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
+    rank.resize(num_nodes);
+    uint32_t ni = 0;
+    for (uint32_t i = 0; i < num_nodes; i++) {
+        if (nodes[i].right > 0) {
+            if ((uint32_t)nodes[i].right >= num_nodes || i + 1 >= num_nodes) { set_err(err, err_len, "pt_flatten_bvh: child index out of range"); return -3; }
+            rank[i] = ni++;
+        } else {
+            uint32_t off = (uint32_t)(-nodes[i].right);
+            if (off % 3 != 0 || off / 3 >= num_triangles) { set_err(err, err_len, "pt_flatten_bvh: leaf offset out of range"); return -3; }
+            rank[i] = off / 3;
+        }
+    }
+    if (ni != num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: interior count is not T-1"); return -2; }
+    return 0;
+}
+
+static uint32_t tree_depth(const PtBVHNode* nodes)
+{
+    /* depth of the deepest node = the most entries a depth-first walk can have pending */
+    uint32_t deepest = 0;
+    std::vector<uint32_t> st = { 0 }, dp = { 0 };
+    while (!st.empty()) {
+        uint32_t i = st.back(), d = dp.back(); st.pop_back(); dp.pop_back();
+        if (d > deepest) deepest = d;
+        if (nodes[i].right > 0) { st.push_back((uint32_t)nodes[i].right); dp.push_back(d + 1); st.push_back(i + 1); dp.push_back(d + 1); }
+    }
+    return deepest;
+}
+
+extern "C" PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
+                                             uint32_t num_triangles, PtNode2c* nodes2, PtTriC* tris, uint32_t* leaf_ref, float* root_box,
+                                             uint32_t* max_stack, char* err, size_t err_len)
+{
+    if (!nodes || !positions || !indices || !tris || !leaf_ref || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh_compact: null argument"); return -1; }
+    std::vector<uint32_t> rank;
+    if (int rc = rank_nodes(nodes, num_nodes, num_triangles, rank, err, err_len)) return rc;
+    auto child_ref = [&](uint32_t i) { return nodes[i].right > 0 ? rank[i] : (PT_LEAF_BIT | rank[i]); };
+
+    for (uint32_t i = 0; i < num_nodes; i++) {
+        const PtBVHNode& n = nodes[i];
+        if (n.right > 0) {
+            PtNode2c& o = nodes2[rank[i]];
+            memset(&o, 0, sizeof(o));
+            const uint32_t child[2] = { i + 1, (uint32_t)n.right };
+            for (int s = 0; s < 2; s++) {
+                float c[3]; uint16_t h[6];
+                digest_box(nodes[child[s]], c, h);
+                for (int k = 0; k < 3; k++) {
+                    o.c[k][s] = c[k];
+                    o.hA[k][s] = h[k];
+                    const int d = (int)h[3 + k] - (int)(h[k] & 0x7FFFu);        /* sign of f16(b-c) must be 0: it is part of the value */
+                    if ((h[3 + k] & 0x8000u) || d < -15 || d > 15) {
+                        set_err(err, err_len, "pt_flatten_bvh_compact: a box does not fit the 48 B encoding");
+                        return 1;
+                    }
+                    o.delta |= (uint32_t)(d + 15) << (5 * k + 16 * s);
+                }
+            }
+            o.left = child_ref(child[0]);
+            o.right = child_ref(child[1]);
+        } else {
+            uint32_t t = rank[i];
+            PtTriC& o = tris[t];
+            uint32_t i1 = indices[3 * (size_t)t], i2 = indices[3 * (size_t)t + 1], i3 = indices[3 * (size_t)t + 2];
+            const float* p1 = positions + 4 * (size_t)i1; const float* p2 = positions + 4 * (size_t)i2; const float* p3 = positions + 4 * (size_t)i3;
+            for (int k = 0; k < 3; k++) { o.p1[k] = p1[k]; o.e1[k] = p2[k] - p1[k]; o.e2[k] = p3[k] - p1[k]; }   /* intersections.glsl:34-35 */
+            o.i1 = (int32_t)i1; o.i2 = (int32_t)i2; o.i3 = (int32_t)i3;
+            leaf_ref[t] = i;
+        }
+    }
+    if (root_box) { for (int k = 0; k < 3; k++) { root_box[k] = nodes[0].a[k]; root_box[3 + k] = nodes[0].b[k]; } }
+    if (max_stack) *max_stack = tree_depth(nodes);
     return 0;
 }
 

@@ -30,6 +30,9 @@
 #ifndef PT_STACK_LDS
 #define PT_STACK_LDS 12          /* per-lane stack entries held in LDS; deeper entries spill to global memory */
 #endif
+#ifndef PT_COMPACT_STRIDE
+#define PT_COMPACT_STRIDE 48     /* distance between 48 B records in memory (64 = padded, an experiment) */
+#endif
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PT_WAVES_PER_BLOCK 4
 #define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
@@ -64,6 +67,8 @@ struct TraceArgs {
     uint32_t         recordBytes;    /* size of that buffer */
     uint32_t         leafBase;       /* byte offset of the first leaf record */
     const uint4*     tris;           /* = records + leafBase/16 */
+    const uint32_t*  leafRef;        /* 48 B records: reference node index of each leaf */
+    uint32_t         lastLeaf;       /* 48 B records: triangle index of the leaf that is the reference array's last node */
     float            rootC[3]; uint16_t rootH[6]; uint32_t rootRef;
     uint2*           overflow;       /* [entry][global lane] spill area of the LDS stacks */
     uint32_t         overflowEntries;
@@ -302,19 +307,22 @@ __device__ __forceinline__ h16x2 as_h2(uint32_t u) { return __builtin_bit_cast(h
 /* Both children's boxes of one interior record at once: the fields are stored as (left, right) half pairs, so every
  * fp16 operation of intersections.glsl:11-27 runs as one packed instruction on both boxes.  Element-wise the
  * arithmetic is the scalar box_static's, operation for operation. */
-__device__ __forceinline__ void box_pair(const RayRegs& r, h16x2 rx, h16x2 ry, h16x2 rz, u32x4 q0, u32x4 q1, u32x4 q2,
+__device__ __forceinline__ void box_pair(const RayRegs& r, h16x2 rx, h16x2 ry, h16x2 rz, f32x2 cx, f32x2 cy, f32x2 cz,
+                                         h16x2 ax, h16x2 ay, h16x2 az, h16x2 bx, h16x2 by, h16x2 bz,
                                          bool& sL, bool& sR, float& tminL, float& tminR)
 {
-    const float cLx = __uint_as_float(q0.x), cLy = __uint_as_float(q0.y), cLz = __uint_as_float(q0.z);
-    const float cRx = __uint_as_float(q0.w), cRy = __uint_as_float(q1.x), cRz = __uint_as_float(q1.y);
-    f32x2 dx = { r.o.x - cLx, r.o.x - cRx }, dy = { r.o.y - cLy, r.o.y - cRy }, dz = { r.o.z - cLz, r.o.z - cRz };
-    h16x2 ox = __builtin_convertvector(dx, h16x2), oy = __builtin_convertvector(dy, h16x2), oz = __builtin_convertvector(dz, h16x2);
-    h16x2 t0 = (as_h2(q1.z) - ox) * rx, t1 = (as_h2(q2.y) - ox) * rx;
+    /* -O = f16(c - o): negation commutes with both roundings, so a + (-O) is the reference's a - O bit for bit, and
+       the compiler no longer spends an instruction per axis on negating O for its add */
+    /* element by element: written as vector minus splat, the compiler keeps three (o,o) register pairs alive across the
+       whole loop, 16 more VGPRs per lane, which costs a wavefront per SIMD when several of these kernels share the CUs */
+    f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
+    h16x2 nox = __builtin_convertvector(dx, h16x2), noy = __builtin_convertvector(dy, h16x2), noz = __builtin_convertvector(dz, h16x2);
+    h16x2 t0 = (ax + nox) * rx, t1 = (bx + nox) * rx;
     h16x2 tmin = __builtin_elementwise_min(t0, t1), tmax = __builtin_elementwise_max(t0, t1);
-    t0 = (as_h2(q1.w) - oy) * ry; t1 = (as_h2(q2.z) - oy) * ry;
+    t0 = (ay + noy) * ry; t1 = (by + noy) * ry;
     tmin = __builtin_elementwise_max(tmin, __builtin_elementwise_min(t0, t1));
     tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
-    t0 = (as_h2(q2.x) - oz) * rz; t1 = (as_h2(q2.w) - oz) * rz;
+    t0 = (az + noz) * rz; t1 = (bz + noz) * rz;
     tmin = __builtin_elementwise_max(tmin, __builtin_elementwise_min(t0, t1));
     tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
     const float fminL = (float)tmin.x, fminR = (float)tmin.y, fmaxL = (float)tmax.x, fmaxR = (float)tmax.y;
@@ -322,8 +330,17 @@ __device__ __forceinline__ void box_pair(const RayRegs& r, h16x2 rx, h16x2 ry, h
     sR = (fmaxR > 0.0f || fminR > 0.0f) && fmaxR >= fminR && r.min_t < fmaxR;
     tminL = fminL; tminR = fminR;
 }
+__device__ __forceinline__ f32x2 as_f2(uint32_t lo, uint32_t hi) { f32x2 v = { __uint_as_float(lo), __uint_as_float(hi) }; return v; }
 
-template <int MODE, bool ANYHIT, bool ORDERED, bool COUNT>
+/* f16(b-c) of both children for one axis of a 48 B record: magnitude bits of f16(a-c) plus the stored 5-bit difference
+ * (biased by 15), sign 0.  Both halves at once: neither the sum nor the bias removal carries across the halves,
+ * because each half's result is a valid non-negative fp16 pattern by construction. */
+__device__ __forceinline__ h16x2 rebuild_b(uint32_t aPair, uint32_t delta, int axis)
+{
+    return as_h2((aPair & 0x7FFF7FFFu) + ((delta >> (5 * axis)) & 0x001F001Fu) + 0xFFF0FFF1u);
+}
+
+template <int MODE, bool ANYHIT, bool ORDERED, bool COUNT, bool COMPACT>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
 {
     __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
@@ -343,6 +360,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1; uint32_t hitLeaf = 0;     /* ids come with the leaf record: no second fetch when the ray ends */
     float alpha = 0, beta = 0, gamma = 0;
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+#ifdef PT_EXPERIMENT_SAMELINE
+    uint32_t prevLine = 0xFFFFFFFFu;
+#endif
 #ifdef PT_EXPERIMENT_TIMING
     unsigned long long tFetch = 0, tIter = 0, nIter = 0, nLaneSteps = 0, t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -360,7 +380,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
             if (!active && nid != ~0ull) {
                 id = nid;
                 if (load_ray<MODE>(a, id, r, exclude, tag)) {
+#ifdef PT_EXPERIMENT_SAMELINE
+                    if (COUNT) { nRay++; prevLine = 0xFFFFFFFFu; }
+#else
                     if (COUNT) { nRay++; nBox++; }
+#endif
+                    /* origBvhId is a reference node index (a leaf's); 48 B records are told apart by their reference */
+                    if (COMPACT && exclude != 0) exclude = PT_LEAF_BIT | ((uint32_t)(-a.nodes[exclude].right) / 3u);
                     hit = false; ranOff = false; sp = 0;
                     rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
                     float ftmin;
@@ -376,25 +402,40 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 empty asm keeps the compiler from splitting them into narrower per-branch loads, which cost twice
                 the L2 requests), then run two box tests or one triangle test ---- */
         const bool leaf = (cur & PT_LEAF_BIT) != 0;
-        const uint32_t off = ((cur & ~PT_LEAF_BIT) << 6) + (leaf ? a.leafBase : 0u);
+        const uint32_t off = (cur & ~PT_LEAF_BIT) * (COMPACT ? (uint32_t)PT_COMPACT_STRIDE : 64u) + (leaf ? a.leafBase : 0u);
 #ifdef PT_EXPERIMENT_TIMING
         unsigned long long ta = __builtin_amdgcn_s_memtime();
 #endif
         u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
         u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
-        u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
-        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+        u32x4 q3 = { 0u, 0u, 0u, 0u };
+        if (COMPACT) {
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+        } else {
+            q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
+            asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+        }
+#ifdef PT_EXPERIMENT_EXTRA_LOAD
+        { u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0); asm volatile("" :: "v"(q4)); }   /* diagnostic: cost of one more 16 B access to the same line */
+#endif
 #ifdef PT_EXPERIMENT_TIMING
         unsigned long long tb_ = __builtin_amdgcn_s_memtime();
         { unsigned long long am = __ballot(true); if (lane == __ffsll(am) - 1) { tFetch += tb_ - ta; nIter++; nLaneSteps += __popcll(am); } }
 #endif
         if (COUNT) nRec++;
+#ifdef PT_EXPERIMENT_SAMELINE
+        /* diagnostic: the box-test counter counts steps whose record lies in the 128 B line of the previous step's */
+        if (COUNT) { if ((off >> 7) == prevLine) nBox++; prevLine = off >> 7; }
+#endif
         bool needPop = true, done = false;
 
         if (leaf) {
-            if (q3.y & 1u) ranOff = true;                                   /* the reference array's last node was entered */
-            if (exclude == 0 || exclude != q3.x) {                          /* intersections.glsl:81 */
+            /* the reference array's last node was entered; which leaf this is: its reference index (64 B record) or
+               the reference to it (48 B record; `exclude` was translated to the same form when the ray was loaded) */
+            if (COMPACT ? (cur == (PT_LEAF_BIT | a.lastLeaf)) : ((q3.y & 1u) != 0)) ranOff = true;
+            const uint32_t leafId = COMPACT ? cur : q3.x;
+            if (exclude == 0 || exclude != leafId) {                        /* intersections.glsl:81 */
                 if (COUNT) nTri++;
                 float t, al, be, ga;
                 F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
@@ -404,17 +445,28 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                     r.max_t = t; alpha = al; beta = be; gamma = ga;
                     hit = true;
                     if (MODE != MODE_SHADOW) { hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w; }
-                    if (MODE == MODE_JOBS) hitLeaf = q3.x;
+                    if (MODE == MODE_JOBS) hitLeaf = leafId;
                     if (ANYHIT) { done = true; needPop = false; }
                 }
             }
         } else {
+#ifndef PT_EXPERIMENT_SAMELINE
             if (COUNT) nBox += 2;
+#endif
             bool sL, sR; float tminL, tminR;
-            box_pair(r, rx, ry, rz, q0, q1, q2, sL, sR, tminL, tminR);
+            uint32_t refL, refR;
+            if (COMPACT) {
+                box_pair(r, rx, ry, rz, as_f2(q0.x, q0.y), as_f2(q0.z, q0.w), as_f2(q1.x, q1.y), as_h2(q1.z), as_h2(q1.w), as_h2(q2.x),
+                         rebuild_b(q1.z, q2.w, 0), rebuild_b(q1.w, q2.w, 1), rebuild_b(q2.x, q2.w, 2), sL, sR, tminL, tminR);
+                refL = q2.y; refR = q2.z;
+            } else {
+                box_pair(r, rx, ry, rz, as_f2(q0.x, q0.y), as_f2(q0.z, q0.w), as_f2(q1.x, q1.y), as_h2(q1.z), as_h2(q1.w), as_h2(q2.x),
+                         as_h2(q2.y), as_h2(q2.z), as_h2(q2.w), sL, sR, tminL, tminR);
+                refL = q3.x; refR = q3.y;
+            }
             const bool pL = sL && r.max_t > tminL, pR = sR && r.max_t > tminR;
-            uint32_t first = q3.x, second = q3.y; float tminSecond = tminR;
-            if (ORDERED && pL && pR && tminR < tminL) { first = q3.y; second = q3.x; tminSecond = tminL; }
+            uint32_t first = refL, second = refR; float tminSecond = tminR;
+            if (ORDERED && pL && pR && tminR < tminL) { first = refR; second = refL; tminSecond = tminL; }
             if (pL && pR) {
                 /* the sibling waits with its tmin; `max_t > tmin` is re-evaluated when it is popped */
                 const uint16_t tb = hbits((h16)tminSecond);                 /* exact: tmin came from an fp16 */
@@ -422,8 +474,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, tb);
                 sp++;
                 cur = first; needPop = false;
-            } else if (pL) { cur = q3.x; needPop = false; }
-            else if (pR) { cur = q3.y; needPop = false; }
+            } else if (pL) { cur = refL; needPop = false; }
+            else if (pR) { cur = refR; needPop = false; }
         }
 
         /* pending siblings come off the stack until one still passes `max_t > tmin` */
@@ -440,7 +492,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         }
 
         if (done) {
-            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, (MODE == MODE_JOBS && ranOff && hit) ? hitLeaf : 0u);
+            uint32_t orig = 0u;
+            if (MODE == MODE_JOBS && ranOff && hit) orig = COMPACT ? a.leafRef[hitLeaf & ~PT_LEAF_BIT] : hitLeaf;
+            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
             active = false;
         }
     }

@@ -18,6 +18,7 @@ ap.add_argument("--blocks", type=str, default="6")
 ap.add_argument("--refill", type=str, default="24")
 ap.add_argument("--modes", type=str, default="0,1,2")
 ap.add_argument("--chunk", type=str, default="0")
+ap.add_argument("--layout", type=int, default=0, help="0 = 64 B records, 1 = 48 B records when encodable")
 ap.add_argument("--scene", type=str, default="courtyard")
 args = ap.parse_args()
 
@@ -33,6 +34,7 @@ t = time.time()
 nodes, ridx, depth = pt.build_bvh(pos, idx, 16)
 print(f"bvh: {nodes.shape[0]} nodes depth {depth} in {time.time()-t:.1f}s", flush=True)
 ctx = pt.PathTracer(0)
+ctx.set_option(core.OPT_RECORD_LAYOUT, args.layout)
 t = time.time()
 ctx.upload_scene(pos, aux, ridx, nodes)
 print(f"upload+flatten {time.time()-t:.1f}s", flush=True)

@@ -152,7 +152,7 @@ def test_flatten_pass(bunny):
     for k, (side, child) in enumerate((("L", interior + 1), ("R", nodes["right"][interior]))):
         a, b = nodes["a"][child], nodes["b"][child]
         c = ((a + b) * np.float32(0.5)).astype(np.float32)
-        assert np.array_equal(n2["c" + side], c)
+        assert np.array_equal(n2["c"][:, :, k], c)
         h = np.concatenate([(a - c).astype(np.float16), (b - c).astype(np.float16)], axis=1).view(np.uint16)
         assert np.array_equal(n2["h"][:, :, k], h)
     # triangles inline, edges as fp32 differences
@@ -255,3 +255,37 @@ def test_write_ppm(tmp_path):
     raw = (tmp_path / "a.ppm").read_bytes()
     assert raw.startswith(b"P6\n5 3\n255\n")
     assert raw[len(b"P6\n5 3\n255\n"):] == img[..., :3].tobytes()
+
+
+@pytest.mark.parametrize("fixture", ["bunny", "monkey", "courtyard_small"])
+def test_flatten_pass_compact_records_decode_to_the_wide_ones(request, fixture):
+    """The 48 B records hold what the 64 B records hold: f16(b-c) rebuilt from f16(a-c) and the stored difference the
+    way the kernel does it equals the stored halves of the 64 B record, and every other field is the same."""
+    m = request.getfixturevalue(fixture)
+    n2, tr, rb, ms = pt.flatten_bvh(m["nodes"], m["positions"], m["indices"])
+    out = pt.flatten_bvh_compact(m["nodes"], m["positions"], m["indices"])
+    assert out is not None, "a box of this model does not fit the 48 B encoding"
+    c2, ct, leaf_ref, rb2, ms2 = out
+    assert ms2 == ms and np.array_equal(rb, rb2)
+    assert np.array_equal(c2["c"], n2["c"]) and np.array_equal(c2["left"], n2["left"]) and np.array_equal(c2["right"], n2["right"])
+    assert np.array_equal(c2["hA"], n2["h"][:, :3, :])
+    a_pair = c2["hA"].astype(np.uint32)
+    a_pair = a_pair[:, :, 0] | (a_pair[:, :, 1] << 16)                                    # [n, axis] (left, right) halves
+    for k in range(3):
+        b_pair = ((a_pair[:, k] & 0x7FFF7FFF) + ((c2["delta"] >> (5 * k)) & 0x001F001F) + np.uint32(0xFFF0FFF1)).astype(np.uint32)
+        assert np.array_equal(b_pair & 0xFFFF, n2["h"][:, 3 + k, 0])
+        assert np.array_equal(b_pair >> 16, n2["h"][:, 3 + k, 1])
+    for f in ("p1", "e1", "e2", "i1", "i2", "i3"):
+        assert np.array_equal(ct[f], tr[f])
+    assert np.array_equal(leaf_ref, tr["refLeaf"])
+
+
+def test_flatten_pass_compact_refuses_a_box_it_cannot_encode(bunny):
+    """A box far from the origin and thin against its distance: the rounding of the centre moves f16(a-c) and f16(b-c)
+    apart by more than the 5-bit field holds.  The pass must say so instead of writing a wrong record."""
+    nodes = bunny["nodes"].copy()
+    k = int(np.nonzero(nodes["right"] > 0)[0][3]) + 1            # a left child somewhere in the tree
+    nodes["a"][k] = (4096.0, 0.0, 0.0)
+    nodes["b"][k] = (4096.0 + 2.0 ** -11 * 3, 1.0, 1.0)
+    assert pt.flatten_bvh_compact(nodes, bunny["positions"], bunny["indices"]) is None
+    pt.flatten_bvh(nodes, bunny["positions"], bunny["indices"])  # the 64 B pass takes any box

@@ -322,3 +322,8 @@ def test_cornell_box_512_four_bounces(gpu_ctx, oracle_lib):
         _compare(gpu_ctx, fr)
     acc = gpu_ctx.readback_accumulation()
     assert (acc[..., :3].sum(axis=2) > 0).mean() > 0.3          # the box is in view and lit
+    # this small tree also exercises the walk that runs off the end of the node array and arms origBvhId
+    # (intersections.glsl:109-113): the shadow rays of such hits skip the leaf they start on
+    rays = helpers.random_rays(nodes[0]["a"], nodes[0]["b"], 20000, seed=1)
+    _, ran = osc.trace(rays, want_ranoff=True)
+    assert (ran != 0).mean() > 0.01
