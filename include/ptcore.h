@@ -215,6 +215,10 @@ enum {
                                     can be encoded (pt_flatten_bvh_compact), else 64 B.  Results do not depend on it;
                                     48 B records save a quarter of the record memory and measure about 5 % slower
                                     (one record in four then lies across two 128 B lines) */
+    PT_OPT_SORT_RAYS      = 9,   /* pt_trace_rays orders a batch by the cell of the scene box each origin lies in before
+                                    tracing it (results are stored under the rays' own indices and do not change):
+                                    0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
+    PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 3): the ordering grid has 2^bits cells per axis */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..4 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and pair of streams; results do not depend on it */
 };

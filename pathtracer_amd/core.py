@@ -35,6 +35,8 @@ assert (LIGHT_DT.itemsize, AUX_DT.itemsize, SLOT_DT.itemsize, CONST_DT.itemsize)
 
 OPT_TRAVERSAL, OPT_STALE_SLOTS, OPT_RESEED, OPT_PERSIST_BLOCKS, OPT_REFILL_MIN, OPT_CLAIM_CHUNK = 1, 2, 3, 4, 5, 6
 OPT_FRAMES_IN_FLIGHT = 7
+OPT_SORT_RAYS = 9               # 0 = never, 1 = always, 2 = batches of 2^20 rays or more (default)
+OPT_SORT_BITS = 10
 OPT_RECORD_LAYOUT = 8           # 0 = 64 B records (default), 1 = 48 B records when every box can be encoded
 TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED = 0, 1, 2
 

@@ -15,6 +15,7 @@
 
 #include "../../include/ptcore.h"
 #include "frame_kernels.h"
+#include "sort_kernels.h"
 #include "trace_kernels.h"
 
 namespace {
@@ -97,9 +98,12 @@ struct PtContext {
     bool accumEmpty = true;     /* no sample in the accumulation since pt_resize / pt_clear_accumulation */
     float4* dAccum = nullptr; uint2* dCurrent = nullptr;
     uint32_t* dFetch = nullptr; unsigned long long* dStats = nullptr;      /* pt_trace_rays: id counter, visit statistics */
+    PtRay* dSortRays = nullptr; uint32_t* dSortPerm = nullptr; uint16_t* dSortKeys = nullptr; uint32_t* dSortBins = nullptr;   /* ray ordering: scratch for sortCapacity rays, [0..4096) counts, [4096..8192) cursors */
+    uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4;
+    bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
 
@@ -137,7 +141,12 @@ void free_frame(PtContext* c)
     c->rngPipe = c->lastPipe = c->resolvePipe = 0;
 }
 
-int grid_blocks(PtContext* c) { return c->numCUs * c->optBlocksPerCU; }
+/* Launch shape of the persistent traversal kernels.  Batches ordered by origin cell run best with one more workgroup per
+ * CU and earlier refills (their lanes share lines, so more of them in flight cost less); both are overridden by
+ * PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN. */
+int blocks_per_cu(PtContext* c, bool ordered) { return (ordered && !c->userBlocks) ? 6 : c->optBlocksPerCU; }
+int refill_min(PtContext* c, bool ordered) { return (ordered && !c->userRefill) ? 24 : c->optRefillMin; }
+int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 6 || c->userBlocks ? c->optBlocksPerCU : 6); }   /* sizes the spill areas */
 
 /* Spill areas of the LDS stacks: one per traversal kernel that can be running at a time, that is two per pipe
  * (closest-hit pass and shadow pass side by side). */
@@ -176,7 +185,9 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
     a.overflowEntries = ctx->overflowEntries;
-    dim3 grid(grid_blocks(ctx)), block(PT_BLOCK);
+    const bool ordered = a.perm != nullptr;
+    dim3 grid(ctx->numCUs * blocks_per_cu(ctx, ordered)), block(PT_BLOCK);
+    a.refillMin = (uint32_t)refill_min(ctx, ordered);
     const int trav = ctx->optTraversal;
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
@@ -320,6 +331,7 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
     free_scene(ctx); free_frame(ctx);
     for (FramePipe& p : ctx->pipe) destroy_pipe(ctx, p);
     dfree(ctx->dFetch); dfree(ctx->dStats);
+    dfree(ctx->dSortRays); dfree(ctx->dSortPerm); dfree(ctx->dSortKeys); dfree(ctx->dSortBins);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
@@ -344,10 +356,12 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_TRAVERSAL: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_TRAVERSAL must be 0, 1 or 2"); ctx->optTraversal = value; return 0;
         case PT_OPT_STALE_SLOTS: ctx->optStale = value != 0; return 0;
         case PT_OPT_RESEED: ctx->optReseed = value != 0; return 0;
-        case PT_OPT_PERSIST_BLOCKS: if (value < 1 || value > 8) return ctx->fail(-1, "PT_OPT_PERSIST_BLOCKS must be 1..8"); ctx->optBlocksPerCU = value; return 0;
-        case PT_OPT_REFILL_MIN: if (value < 1 || value > 64) return ctx->fail(-1, "PT_OPT_REFILL_MIN must be 1..64"); ctx->optRefillMin = value; return 0;
+        case PT_OPT_PERSIST_BLOCKS: if (value < 1 || value > 8) return ctx->fail(-1, "PT_OPT_PERSIST_BLOCKS must be 1..8"); ctx->optBlocksPerCU = value; ctx->userBlocks = true; return 0;
+        case PT_OPT_REFILL_MIN: if (value < 1 || value > 64) return ctx->fail(-1, "PT_OPT_REFILL_MIN must be 1..64"); ctx->optRefillMin = value; ctx->userRefill = true; return 0;
         case PT_OPT_CLAIM_CHUNK: if (value < 0 || value > 1024 || value % 64) return ctx->fail(-1, "PT_OPT_CLAIM_CHUNK must be 0 or a multiple of 64 up to 1024"); ctx->optClaimChunk = value; return 0;
         case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0 or 1"); ctx->optRecordLayout = value; return 0;
+        case PT_OPT_SORT_BITS: if (value < 1 || value > 4) return ctx->fail(-1, "PT_OPT_SORT_BITS must be 1..4"); ctx->optSortBits = value; return 0;
+        case PT_OPT_SORT_RAYS: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SORT_RAYS must be 0, 1 or 2"); ctx->optSortRays = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..4"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
@@ -363,6 +377,8 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_REFILL_MIN: *value = ctx->optRefillMin; return 0;
         case PT_OPT_CLAIM_CHUNK: *value = ctx->optClaimChunk; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: *value = ctx->optFramesInFlight; return 0;
+        case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
+        case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;
         case PT_OPT_RECORD_LAYOUT: *value = ctx->optRecordLayout; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
@@ -766,6 +782,34 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
     if (stats) HIPCHK(hipMemsetAsync(ctx->dStats, 0, 32, ctx->stream));
     TraceArgs a; fill_trace_args(ctx, a);
     a.rays = d_rays; a.hits = d_hits; a.count = num_rays; a.countPtr = nullptr; a.fetchCounter = ctx->dFetch;
+    /* large batches are first ordered by the cell of the scene box their origin lies in (sort_kernels.h) */
+    const bool sort = ctx->optSortRays == 1 || (ctx->optSortRays == 2 && num_rays >= (1u << 20));
+    if (sort) {
+        if (ctx->sortCapacity < num_rays) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->dSortRays); dfree(ctx->dSortPerm); dfree(ctx->dSortKeys); ctx->sortCapacity = 0;
+            HIPCHK(hipMalloc((void**)&ctx->dSortRays, num_rays * sizeof(PtRay)));
+            HIPCHK(hipMalloc((void**)&ctx->dSortPerm, num_rays * 4));
+            HIPCHK(hipMalloc((void**)&ctx->dSortKeys, num_rays * 2));
+            ctx->sortCapacity = num_rays;
+        }
+        if (!ctx->dSortBins) {
+            HIPCHK(hipMalloc((void**)&ctx->dSortBins, 2 * PT_SORT_BINS * 4));
+            HIPCHK(hipMemsetAsync(ctx->dSortBins, 0, 2 * PT_SORT_BINS * 4, ctx->stream));
+        }
+        const float* b = ctx->rootBox;
+        const float cells = (float)(1 << ctx->optSortBits);
+        const int nbins = 1 << (3 * ctx->optSortBits);
+        auto scale = [cells](float lo, float hi) { float d = hi - lo; return d > 0.0f ? cells / d : 0.0f; };
+        const uint32_t tiles = (uint32_t)((num_rays + PT_SORT_TILE - 1) / PT_SORT_TILE);
+        hipLaunchKernelGGL(k_bin_count, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, d_rays, num_rays, ctx->dSortKeys, ctx->dSortBins, nbins,
+                           b[0], b[1], b[2], scale(b[0], b[3]), scale(b[1], b[4]), scale(b[2], b[5]), cells - 1.0f);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(PT_SORT_BLOCK), 0, ctx->stream, ctx->dSortBins, ctx->dSortBins + PT_SORT_BINS);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, d_rays, num_rays, ctx->dSortKeys,
+                           ctx->dSortBins + PT_SORT_BINS, nbins, ctx->dSortRays, ctx->dSortPerm);
+        HIPCHK(hipGetLastError());
+        a.rays = ctx->dSortRays; a.perm = ctx->dSortPerm;
+    }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);
     if (rc) return rc;

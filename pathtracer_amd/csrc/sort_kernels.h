@@ -1,0 +1,109 @@
+/*
+ * sort_kernels.h — orders a batch of rays by the cell of the scene box their origin lies in, so that the lanes of a
+ * wavefront, and the wavefronts that run side by side, walk neighbouring parts of the tree and share its lines in
+ * the caches.  A ray's result does not depend on where in the batch it is traced, and results are stored under the
+ * ray's own index, so the order only changes speed.
+ *
+ * One counting-sort pass over a grid of 2^bits cells per axis (bits <= 4, Morton key of 3*bits bits):
+ *   k_bin_count    per tile of rays: key of every ray (kept for the scatter pass), tile histogram in LDS, one global
+ *                  atomic per non-empty bin of the tile
+ *   k_bin_scan     exclusive prefix sum of the 4096 bin counts (one workgroup)
+ *   k_bin_scatter  per tile: reserves the tile's slice of every bin with one global atomic, ranks the tile's rays
+ *                  inside the slice with LDS atomics, writes each ray and its original index to its sorted place
+ * The order of rays inside a bin depends on the order of atomics and differs from run to run; nothing observable does.
+ */
+#pragma once
+#include "../../include/ptcore.h"
+
+#define PT_SORT_BINS 4096
+#define PT_SORT_TILE 32768
+#define PT_SORT_BLOCK 1024
+
+__device__ __forceinline__ uint32_t spread4(uint32_t v)      /* bits 0..3 of v to bits 0,3,6,9 */
+{
+    return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+__device__ __forceinline__ uint32_t ray_bin(const float4 o, float lox, float loy, float loz, float sx, float sy, float sz, float top)
+{
+    /* NaN and out-of-box origins clamp into the grid: any bin is a valid place for a ray */
+    int cx = (int)fminf(fmaxf((o.x - lox) * sx, 0.0f), top);
+    int cy = (int)fminf(fmaxf((o.y - loy) * sy, 0.0f), top);
+    int cz = (int)fminf(fmaxf((o.z - loz) * sz, 0.0f), top);
+    return spread4((uint32_t)cx) | (spread4((uint32_t)cy) << 1) | (spread4((uint32_t)cz) << 2);
+}
+
+__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_count(const PtRay* rays, uint64_t n, uint16_t* keys, uint32_t* binCount, int nbins,
+                                                            float lox, float loy, float loz, float sx, float sy, float sz, float top)
+{
+    __shared__ uint32_t hist[PT_SORT_BINS];
+    for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) hist[b] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PT_SORT_TILE;
+    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += PT_SORT_BLOCK) {
+        const uint64_t i = base + k;
+        if (i < n) {
+            const uint32_t bin = ray_bin(*(const float4*)(rays + i), lox, loy, loz, sx, sy, sz, top);
+            keys[i] = (uint16_t)bin;
+            atomicAdd(&hist[bin], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) { uint32_t c = hist[b]; if (c) atomicAdd(binCount + b, c); }
+}
+
+/* binStart[b] = number of rays in bins < b; cursor starts as a copy; binCount is cleared for the next batch. */
+__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scan(uint32_t* binCount, uint32_t* cursor)
+{
+    __shared__ uint32_t part[PT_SORT_BLOCK];
+    const int t = threadIdx.x, per = PT_SORT_BINS / PT_SORT_BLOCK;
+    uint32_t c[per], s = 0;
+    for (int k = 0; k < per; k++) { c[k] = binCount[t * per + k]; s += c[k]; }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < PT_SORT_BLOCK; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int k = 0; k < per; k++) { cursor[t * per + k] = run; run += c[k]; binCount[t * per + k] = 0; }
+}
+
+__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(const PtRay* rays, uint64_t n, const uint16_t* keys, uint32_t* cursor, int nbins,
+                                                              PtRay* sorted, uint32_t* perm)
+{
+    __shared__ uint32_t hist[PT_SORT_BINS];       /* first the tile's count per bin, then the next free place in the tile's slice */
+    for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) hist[b] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * PT_SORT_TILE;
+    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += PT_SORT_BLOCK) {
+        const uint64_t i = base + k;
+        if (i < n) atomicAdd(&hist[keys[i]], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) { uint32_t c = hist[b]; hist[b] = c ? atomicAdd(cursor + b, c) : 0u; }
+    __syncthreads();
+    /* four rays per lane and turn: their loads are in flight together */
+    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += 4 * PT_SORT_BLOCK) {
+        uint32_t dst[4]; float4 q0[4], q1[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint64_t i = base + k + u * PT_SORT_BLOCK;
+            ok[u] = i < n;
+            if (ok[u]) {
+                const float4* p = (const float4*)(rays + i);
+                q0[u] = p[0]; q1[u] = p[1];
+                dst[u] = atomicAdd(&hist[keys[i]], 1u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (ok[u]) {
+                float4* o = (float4*)(sorted + dst[u]);
+                o[0] = q0[u]; o[1] = q1[u];
+                perm[dst[u]] = (uint32_t)(base + k + u * PT_SORT_BLOCK);
+            }
+        }
+    }
+}

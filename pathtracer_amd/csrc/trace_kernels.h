@@ -80,6 +80,7 @@ struct TraceArgs {
     uint32_t         claimChunk;     /* ids a wavefront takes from the counter at a time (0: chosen from the ray count) */
     /* MODE_RAYS */
     const PtRay*     rays;  PtHit* hits;
+    const uint32_t*  perm;           /* rays[] was reordered: ray k's result goes to hits[perm[k]] (nullptr: to hits[k]) */
     /* MODE_JOBS */
     const uint32_t*  jobs;  PtRayStackSlot* stack;  PtHitRec* hitRecs;
     /* MODE_SHADOW */
@@ -90,36 +91,59 @@ struct TraceArgs {
 
 /* ---- per-mode ray fetch / result store ------------------------------------------------------- */
 
+/* A ray is fetched in two halves so that the traversal loop can issue the loads of new rays, go on with a step of
+ * the rays it already has, and only then turn the loaded words into a ray: the loads then cost no round trip of their
+ * own.  issue_ray returns false for a dead job (nothing was loaded). */
+struct RayWords { float4 w0, w1; uint32_t tag; };
+
 template <int MODE>
-__device__ __forceinline__ bool load_ray(const TraceArgs& a, uint64_t id, RayRegs& r, uint32_t& exclude, uint32_t& tag)
+__device__ __forceinline__ bool issue_ray(const TraceArgs& a, uint64_t id, RayWords& w)
 {
     if (MODE == MODE_RAYS) {
         const float4* p = (const float4*)(a.rays + id);
-        float4 q0 = p[0], q1 = p[1];
-        r.o = { q0.x, q0.y, q0.z }; r.min_t = q0.w;
-        ray_set_dir(r, { q1.x, q1.y, q1.z }); r.max_t = q1.w;
-        exclude = 0; tag = 0;
+        w.w0 = p[0]; w.w1 = p[1]; w.tag = a.perm ? a.perm[id] : 0u;
         return true;
     } else if (MODE == MODE_JOBS) {
         uint32_t slot = a.jobs[id];
         if (slot == PT_JOB_DEAD) return false;
         const float4* p = (const float4*)(a.stack + slot);                  /* trace.comp:185-190 */
-        float4 q0 = p[0], q1 = p[1];
-        ray_set_dir(r, { q0.x, q0.y, q0.z });
-        r.o = { q1.x, q1.y, q1.z };
-        r.min_t = 0.001f; r.max_t = 100000.0f;
-        exclude = 0; tag = slot;
+        w.w0 = p[0]; w.w1 = p[1]; w.tag = slot;
         return true;
     } else {
         const float4* p = (const float4*)(a.shadowRays + id);
-        float4 q0 = p[0], q1 = p[1];
-        uint32_t slot = a.shadowRays[id].slot;
-        r.o = { q0.x, q0.y, q0.z }; r.max_t = q0.w;
-        ray_set_dir(r, { q1.x, q1.y, q1.z });
-        r.min_t = 0.001f;
-        exclude = __float_as_uint(q1.w); tag = slot;
+        w.w0 = p[0]; w.w1 = p[1]; w.tag = a.shadowRays[id].slot;
         return true;
     }
+}
+
+template <int MODE>
+__device__ __forceinline__ void finish_ray(const RayWords& w, RayRegs& r, uint32_t& exclude, uint32_t& tag)
+{
+    tag = w.tag;
+    if (MODE == MODE_RAYS) {
+        r.o = { w.w0.x, w.w0.y, w.w0.z }; r.min_t = w.w0.w;
+        ray_set_dir(r, { w.w1.x, w.w1.y, w.w1.z }); r.max_t = w.w1.w;
+        exclude = 0;
+    } else if (MODE == MODE_JOBS) {
+        ray_set_dir(r, { w.w0.x, w.w0.y, w.w0.z });
+        r.o = { w.w1.x, w.w1.y, w.w1.z };
+        r.min_t = 0.001f; r.max_t = 100000.0f;
+        exclude = 0;
+    } else {
+        r.o = { w.w0.x, w.w0.y, w.w0.z }; r.max_t = w.w0.w;
+        ray_set_dir(r, { w.w1.x, w.w1.y, w.w1.z });
+        r.min_t = 0.001f;
+        exclude = __float_as_uint(w.w1.w);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ bool load_ray(const TraceArgs& a, uint64_t id, RayRegs& r, uint32_t& exclude, uint32_t& tag)
+{
+    RayWords w;
+    if (!issue_ray<MODE>(a, id, w)) return false;
+    finish_ray<MODE>(w, r, exclude, tag);
+    return true;
 }
 
 template <int MODE>
@@ -130,7 +154,7 @@ __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, ui
         float4 o;
         o.x = t;
         o.y = __int_as_float(hit ? i1 : -1); o.z = __int_as_float(hit ? i2 : -1); o.w = __int_as_float(hit ? i3 : -1);
-        *(float4*)(a.hits + id) = o;
+        *(float4*)(a.hits + (a.perm ? (uint64_t)tag : id)) = o;
     } else if (MODE == MODE_JOBS) {
         uint4 o0, o1;
         o0.x = __float_as_uint(t);
@@ -370,34 +394,41 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
 
+    /* turns the words a lane loaded into its next ray: root box test, traversal state */
+    auto start_ray = [&](const RayWords& w) {
+        finish_ray<MODE>(w, r, exclude, tag);
+#ifdef PT_EXPERIMENT_SAMELINE
+        if (COUNT) { nRay++; prevLine = 0xFFFFFFFFu; }
+#else
+        if (COUNT) { nRay++; nBox++; }
+#endif
+        /* origBvhId is a reference node index (a leaf's); 48 B records are told apart by their reference */
+        if (COMPACT && exclude != 0) exclude = PT_LEAF_BIT | ((uint32_t)(-a.nodes[exclude].right) / 3u);
+        hit = false; ranOff = false; sp = 0;
+        rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
+        float ftmin;
+        bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
+        if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
+        else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);      /* root box missed */
+    };
+
     for (;;) {
-        /* ---- refill idle lanes from the global ray pool ---- */
+        /* ---- refill: idle lanes take ray ids and issue the loads of their rays; the words are used after the step
+                below, so that these loads and the step's record fetch are one wait ---- */
         uint64_t idleMask = __ballot(!active);
         int nIdle = __popcll(idleMask);
         if (nIdle == 64 && pool.exhausted()) break;
+        bool fresh = false;
+        RayWords w;
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, !active, idleMask, nIdle);
-            if (!active && nid != ~0ull) {
-                id = nid;
-                if (load_ray<MODE>(a, id, r, exclude, tag)) {
-#ifdef PT_EXPERIMENT_SAMELINE
-                    if (COUNT) { nRay++; prevLine = 0xFFFFFFFFu; }
-#else
-                    if (COUNT) { nRay++; nBox++; }
-#endif
-                    /* origBvhId is a reference node index (a leaf's); 48 B records are told apart by their reference */
-                    if (COMPACT && exclude != 0) exclude = PT_LEAF_BIT | ((uint32_t)(-a.nodes[exclude].right) / 3u);
-                    hit = false; ranOff = false; sp = 0;
-                    rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
-                    float ftmin;
-                    bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
-                    if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
-                    else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);      /* root box missed */
-                }
-            }
+            if (!active && nid != ~0ull) { id = nid; fresh = issue_ray<MODE>(a, id, w); }
         }
-        if (!active) continue;
+#ifdef PT_SYNC_REFILL
+        if (fresh) { start_ray(w); fresh = false; }     /* diagnostic: the refill waits for its own loads */
+#endif
 
+        if (active) {
         /* ---- one step: fetch the 64 B record `cur` names with four 16 B buffer loads issued back to back (the
                 empty asm keeps the compiler from splitting them into narrower per-branch loads, which cost twice
                 the L2 requests), then run two box tests or one triangle test ---- */
@@ -497,6 +528,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
             store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
             active = false;
         }
+        }   /* if (active) */
+
+        /* ---- the rays loaded above start here; they step with the others from the next turn ---- */
+        if (fresh) start_ray(w);
     }
 #ifdef PT_EXPERIMENT_TIMING
     /* diagnostic build only: per-wave cycle sums go to the stats words, which nothing else reads in this build */

@@ -18,6 +18,8 @@ ap.add_argument("--blocks", type=str, default="6")
 ap.add_argument("--refill", type=str, default="24")
 ap.add_argument("--modes", type=str, default="0,1,2")
 ap.add_argument("--chunk", type=str, default="0")
+ap.add_argument("--sort", type=int, default=2)
+ap.add_argument("--bits", type=str, default="3")
 ap.add_argument("--layout", type=int, default=0, help="0 = 64 B records, 1 = 48 B records when encodable")
 ap.add_argument("--scene", type=str, default="courtyard")
 args = ap.parse_args()
@@ -54,14 +56,21 @@ for mode in [int(m) for m in args.modes.split(",")]:
     for blocks in [int(b) for b in args.blocks.split(",")]:
         for refill in [int(r) for r in args.refill.split(",")]:
           for chunk in [int(c) for c in args.chunk.split(",")]:
+           for bits in [int(c) for c in args.bits.split(",")]:
+            ctx.set_option(core.OPT_SORT_BITS, bits)
             ctx.set_option(core.OPT_CLAIM_CHUNK, chunk)
+            ctx.set_option(core.OPT_SORT_RAYS, args.sort)
             ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
             ctx.set_option(core.OPT_REFILL_MIN, refill)
             ms = []
+            ctx.synchronize()
+            tw = time.perf_counter()
             for _ in range(args.reps):
                 ctx.trace_rays_device(d_rays, n, d_hits)
                 ms.append(ctx.last_kernel_ms())
+            ctx.synchronize()
+            wall = (time.perf_counter() - tw) / args.reps * 1e3
             best = min(ms)
-            print(f"   blocks/CU {blocks} refill {refill} chunk {chunk}: {best:.2f} ms  {n/best/1e3:.1f} Mrays/s  (all: {', '.join('%.2f'%m for m in ms)})", flush=True)
+            print(f"   blocks/CU {blocks} refill {refill} chunk {chunk} bits {bits} wall/launch {wall:.2f} ms: {best:.2f} ms  {n/best/1e3:.1f} Mrays/s  (all: {', '.join('%.2f'%m for m in ms)})", flush=True)
 d_rays.free(); d_hits.free()
 ctx.close()

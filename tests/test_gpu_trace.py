@@ -223,3 +223,37 @@ def test_full_size_microbench_properties(gpu_ctx):
     finally:
         d_rays.free(); d_a.free(); d_b.free()
         ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+
+
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED])
+def test_ray_ordering_changes_nothing(gpu_ctx, bunny, traversal):
+    """Batches ordered by origin cell before tracing (PT_OPT_SORT_RAYS) return byte for byte what unordered batches
+    return: ragged sizes around the sort's tile, one ray, all origins in one cell (camera rays), origins outside the
+    scene box and non-finite origins."""
+    ctx = gpu_ctx
+    helpers.upload(ctx, bunny)
+    ctx.set_option(core.OPT_TRAVERSAL, traversal)
+    lo, hi = bunny["nodes"][0]["a"], bunny["nodes"][0]["b"]
+    batches = {
+        "random": helpers.random_rays(lo, hi, 3 * 32768 + 17, seed=21),
+        "one": helpers.random_rays(lo, hi, 1, seed=22),
+        "tile+1": helpers.random_rays(lo, hi, 32769, seed=23),
+        "camera": helpers.camera_rays(320, 180),
+        "outside": helpers.random_rays(lo, hi, 50_000, seed=24, inside=False),
+    }
+    odd = helpers.random_rays(lo, hi, 4096, seed=25)
+    odd["o"][::7] = np.nan
+    odd["o"][1::7] = np.inf
+    odd["o"][2::7] *= 1e30
+    batches["non-finite"] = odd
+    try:
+        for name, rays in batches.items():
+            for any_hit in (False, True):
+                ctx.set_option(core.OPT_SORT_RAYS, 0)
+                plain = ctx.trace_rays(rays, any_hit=any_hit)
+                ctx.set_option(core.OPT_SORT_RAYS, 1)
+                ordered = ctx.trace_rays(rays, any_hit=any_hit)
+                assert np.array_equal(plain.view(np.uint8), ordered.view(np.uint8)), f"{name}, any_hit={any_hit}"
+    finally:
+        ctx.set_option(core.OPT_SORT_RAYS, 2)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
