@@ -293,6 +293,11 @@ class PathTracer:
     def set_option(self, opt, value):
         self._chk(self._L.pt_set_option(self._h, opt, int(value)))
 
+    def get_option(self, opt):
+        v = C.c_int(0)
+        self._chk(self._L.pt_get_option(self._h, opt, C.byref(v)))
+        return v.value
+
     def synchronize(self):
         self._chk(self._L.pt_synchronize(self._h))
 

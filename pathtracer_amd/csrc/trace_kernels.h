@@ -4,7 +4,9 @@
  * Two families, both one ray per lane of a 64-wide wavefront, both persistent: a launch is
  * sized to the machine (workgroups per CU x CUs) and every wavefront keeps pulling rays from one
  * global counter until the pool is empty, refilling its idle lanes in batches so that a lane
- * whose ray ended early does not idle for the rest of its wavefront's longest ray.
+ * whose ray ended early does not idle for the rest of its wavefront's longest ray.  A refill has no
+ * wait of its own: the loads of the new rays are issued before the step of the lanes that still
+ * have rays and used after it.
  *
  *  k_trace_ref   walks the reference's threaded 32 B node array exactly as traceRay does
  *                (reference intersections.glsl:57-115): no stack, one dependent 32 B fetch per

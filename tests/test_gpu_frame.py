@@ -217,6 +217,20 @@ def test_error_behaviour(oracle_lib, bunny):
             ctx.set_constants(pt.fill_constants(32, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))   # wrong viewport
         with pytest.raises(pt.PtError):
             ctx.set_option(core.OPT_TRAVERSAL, 9)
+        # every option: a value in range reads back, a value out of range is refused and leaves the option as it was
+        for opt, good, bad in ((core.OPT_TRAVERSAL, 1, 3), (core.OPT_PERSIST_BLOCKS, 4, 0), (core.OPT_REFILL_MIN, 20, 65),
+                               (core.OPT_CLAIM_CHUNK, 256, 100), (core.OPT_FRAMES_IN_FLIGHT, 4, 5), (core.OPT_RECORD_LAYOUT, 1, 2),
+                               (core.OPT_SORT_RAYS, 1, 3), (core.OPT_SORT_BITS, 2, 5)):
+            ctx.set_option(opt, good)
+            assert ctx.get_option(opt) == good
+            with pytest.raises(pt.PtError):
+                ctx.set_option(opt, bad)
+            assert ctx.get_option(opt) == good
+        with pytest.raises(pt.PtError):
+            ctx.set_option(99, 0)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        with pytest.raises(pt.PtError):
+            ctx.set_constants(pt.fill_constants(64, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0] + 2))   # wrong node count
         ctx.set_constants(pt.fill_constants(64, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))
         ctx.render_sample(1)
         assert (ctx.readback_accumulation()[..., 3] == 1).all()
