@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void k_gather(const void* buf, unsigned long l
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         unsigned idx;
         if (pattern == 3) {
-            // quad-cooperative: in round k the four lanes of a quad read the four 16 B pieces of ONE random record
+            // quad-cooperative: in turn k the four lanes of a quad read the four 16 B pieces of ONE random record
             const unsigned quadBase = i & ~3u, piece = (i & 3u) * 16u;
             for (int k = 0; k < 4; k++) {
                 unsigned id2 = ((quadBase + k) * 2654435761u) & (n - 1);

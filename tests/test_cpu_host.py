@@ -37,7 +37,7 @@ def test_context_needs_a_gpu_and_says_so():
 
 
 def test_struct_layouts_match_reference_contract():
-    # sizes and offsets of SURVEY's data contract (ShaderData.h:9-47, structures.glsl:35-72)
+    # sizes and offsets of the reference's data contract (ShaderData.h:9-47, structures.glsl:35-72)
     assert core.SLOT_DT.fields["randState"][1] == 12 and core.SLOT_DT.fields["rayOrigin"][1] == 16
     assert core.SLOT_DT.fields["currentDepth"][1] == 28 and core.SLOT_DT.fields["hitAlbedo"][1] == 32
     assert core.SLOT_DT.fields["wIn"][1] == 40 and core.SLOT_DT.fields["prob"][1] == 46
