@@ -6,7 +6,8 @@ config "SanMiguel.ply 64M random incoherent rays, pure traversal microbench vs H
 
 One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE).  A step is one
 pass of pt_trace_rays over 2^26 synthetic rays per GPU that are already resident in HBM: the library
-orders the batch by origin cell (a counting sort, three small kernels) and traces it; both are timed.
+builds an order for the batch by origin cell (a counting sort of indices, three small kernels) and
+traces the rays in that order; both are timed.
 The scene is replicated on every GPU and every rank traces its own range of the ray sequence, so
 the path has no data exchange: weak scaling, value = rays of all ranks / max-over-ranks time.
 
@@ -169,8 +170,8 @@ def main():
             "bvh_nodes": int(nodes.shape[0]),
             "traversal": {0: "reference 32 B nodes, stackless", 1: "flattened 64 B records, reference visit order",
                           2: "flattened 64 B records, near child first"}[trav],
-            "ray_ordering": "each batch is ordered by origin cell (16^3 grid over the scene box) inside the timed step, "
-                            "results stored under the rays' own indices",
+            "ray_ordering": "each batch is traced in the order of its origin cells (16^3 grid over the scene box); the order is "
+                            "built inside the timed step, results are stored under the rays' own indices",
             "other_kernels_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 3),
             "hit_rate": round(hit_rate, 4),
             "box_tests_per_ray": round(box_per_ray, 2),

@@ -98,7 +98,7 @@ struct PtContext {
     bool accumEmpty = true;     /* no sample in the accumulation since pt_resize / pt_clear_accumulation */
     float4* dAccum = nullptr; uint2* dCurrent = nullptr;
     uint32_t* dFetch = nullptr; unsigned long long* dStats = nullptr;      /* pt_trace_rays: id counter, visit statistics */
-    PtRay* dSortRays = nullptr; uint32_t* dSortPerm = nullptr; uint16_t* dSortKeys = nullptr; uint32_t* dSortBins = nullptr;   /* ray ordering: scratch for sortCapacity rays, [0..4096) counts, [4096..8192) cursors */
+    uint32_t* dSortOrder = nullptr; uint16_t* dSortKeys = nullptr; uint32_t* dSortBins = nullptr;   /* ray ordering: scratch for sortCapacity rays, [0..4096) counts, [4096..8192) cursors */
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
@@ -185,7 +185,7 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
     a.overflowEntries = ctx->overflowEntries;
-    const bool ordered = a.perm != nullptr;
+    const bool ordered = a.order != nullptr;
     dim3 grid(ctx->numCUs * blocks_per_cu(ctx, ordered)), block(PT_BLOCK);
     a.refillMin = (uint32_t)refill_min(ctx, ordered);
     const int trav = ctx->optTraversal;
@@ -331,7 +331,7 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
     free_scene(ctx); free_frame(ctx);
     for (FramePipe& p : ctx->pipe) destroy_pipe(ctx, p);
     dfree(ctx->dFetch); dfree(ctx->dStats);
-    dfree(ctx->dSortRays); dfree(ctx->dSortPerm); dfree(ctx->dSortKeys); dfree(ctx->dSortBins);
+    dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); dfree(ctx->dSortBins);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
@@ -787,9 +787,8 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
     if (sort) {
         if (ctx->sortCapacity < num_rays) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            dfree(ctx->dSortRays); dfree(ctx->dSortPerm); dfree(ctx->dSortKeys); ctx->sortCapacity = 0;
-            HIPCHK(hipMalloc((void**)&ctx->dSortRays, num_rays * sizeof(PtRay)));
-            HIPCHK(hipMalloc((void**)&ctx->dSortPerm, num_rays * 4));
+            dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); ctx->sortCapacity = 0;
+            HIPCHK(hipMalloc((void**)&ctx->dSortOrder, num_rays * 4));
             HIPCHK(hipMalloc((void**)&ctx->dSortKeys, num_rays * 2));
             ctx->sortCapacity = num_rays;
         }
@@ -805,10 +804,10 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
         hipLaunchKernelGGL(k_bin_count, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, d_rays, num_rays, ctx->dSortKeys, ctx->dSortBins, nbins,
                            b[0], b[1], b[2], scale(b[0], b[3]), scale(b[1], b[4]), scale(b[2], b[5]), cells - 1.0f);
         hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(PT_SORT_BLOCK), 0, ctx->stream, ctx->dSortBins, ctx->dSortBins + PT_SORT_BINS);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, d_rays, num_rays, ctx->dSortKeys,
-                           ctx->dSortBins + PT_SORT_BINS, nbins, ctx->dSortRays, ctx->dSortPerm);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, num_rays, ctx->dSortKeys,
+                           ctx->dSortBins + PT_SORT_BINS, nbins, ctx->dSortOrder);
         HIPCHK(hipGetLastError());
-        a.rays = ctx->dSortRays; a.perm = ctx->dSortPerm;
+        a.order = ctx->dSortOrder;
     }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);

@@ -1,15 +1,17 @@
 /*
- * sort_kernels.h — orders a batch of rays by the cell of the scene box their origin lies in, so that the lanes of a
- * wavefront, and the wavefronts that run side by side, walk neighbouring parts of the tree and share its lines in
- * the caches.  A ray's result does not depend on where in the batch it is traced, and results are stored under the
- * ray's own index, so the order only changes speed.
+ * sort_kernels.h — the order in which a batch of rays is traced: by the cell of the scene box each origin lies in, so
+ * that the wavefronts that run side by side walk neighbouring parts of the tree and share its lines in the caches.
+ * The rays stay where they are; the kernels produce order[k] = index of the k-th ray to trace, and the traversal
+ * kernel fetches its rays through it (moving the rays into order as well costs 2 ms more per 2^26 rays than the
+ * scattered fetch does).  A ray's result does not depend on when it is traced and is stored under the ray's own
+ * index, so the order only changes speed.
  *
  * One counting-sort pass over a grid of 2^bits cells per axis (bits <= 4, Morton key of 3*bits bits):
  *   k_bin_count    per tile of rays: key of every ray (kept for the scatter pass), tile histogram in LDS, one global
  *                  atomic per non-empty bin of the tile
  *   k_bin_scan     exclusive prefix sum of the 4096 bin counts (one workgroup)
  *   k_bin_scatter  per tile: reserves the tile's slice of every bin with one global atomic, ranks the tile's rays
- *                  inside the slice with LDS atomics, writes each ray and its original index to its sorted place
+ *                  inside the slice with LDS atomics, writes each ray's index to its place in the order
  * The order of rays inside a bin depends on the order of atomics and differs from run to run; nothing observable does.
  */
 #pragma once
@@ -70,8 +72,7 @@ __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scan(uint32_t* binCount, 
     for (int k = 0; k < per; k++) { cursor[t * per + k] = run; run += c[k]; binCount[t * per + k] = 0; }
 }
 
-__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(const PtRay* rays, uint64_t n, const uint16_t* keys, uint32_t* cursor, int nbins,
-                                                              PtRay* sorted, uint32_t* perm)
+__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(uint64_t n, const uint16_t* keys, uint32_t* cursor, int nbins, uint32_t* order)
 {
     __shared__ uint32_t hist[PT_SORT_BINS];       /* first the tile's count per bin, then the next free place in the tile's slice */
     for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) hist[b] = 0;
@@ -84,26 +85,8 @@ __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(const PtRay* rays
     __syncthreads();
     for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) { uint32_t c = hist[b]; hist[b] = c ? atomicAdd(cursor + b, c) : 0u; }
     __syncthreads();
-    /* four rays per lane and turn: their loads are in flight together */
-    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += 4 * PT_SORT_BLOCK) {
-        uint32_t dst[4]; float4 q0[4], q1[4]; bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint64_t i = base + k + u * PT_SORT_BLOCK;
-            ok[u] = i < n;
-            if (ok[u]) {
-                const float4* p = (const float4*)(rays + i);
-                q0[u] = p[0]; q1[u] = p[1];
-                dst[u] = atomicAdd(&hist[keys[i]], 1u);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (ok[u]) {
-                float4* o = (float4*)(sorted + dst[u]);
-                o[0] = q0[u]; o[1] = q1[u];
-                perm[dst[u]] = (uint32_t)(base + k + u * PT_SORT_BLOCK);
-            }
-        }
+    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += PT_SORT_BLOCK) {
+        const uint64_t i = base + k;
+        if (i < n) order[atomicAdd(&hist[keys[i]], 1u)] = (uint32_t)i;
     }
 }

@@ -82,7 +82,7 @@ struct TraceArgs {
     uint32_t         claimChunk;     /* ids a wavefront takes from the counter at a time (0: chosen from the ray count) */
     /* MODE_RAYS */
     const PtRay*     rays;  PtHit* hits;
-    const uint32_t*  perm;           /* rays[] was reordered: ray k's result goes to hits[perm[k]] (nullptr: to hits[k]) */
+    const uint32_t*  order;          /* the k-th ray to trace is rays[order[k]] (nullptr: rays[k]) */
     /* MODE_JOBS */
     const uint32_t*  jobs;  PtRayStackSlot* stack;  PtHitRec* hitRecs;
     /* MODE_SHADOW */
@@ -102,8 +102,8 @@ template <int MODE>
 __device__ __forceinline__ bool issue_ray(const TraceArgs& a, uint64_t id, RayWords& w)
 {
     if (MODE == MODE_RAYS) {
-        const float4* p = (const float4*)(a.rays + id);
-        w.w0 = p[0]; w.w1 = p[1]; w.tag = a.perm ? a.perm[id] : 0u;
+        const float4* p = (const float4*)(a.rays + id);          /* id: the ray's own index */
+        w.w0 = p[0]; w.w1 = p[1]; w.tag = 0;
         return true;
     } else if (MODE == MODE_JOBS) {
         uint32_t slot = a.jobs[id];
@@ -156,7 +156,7 @@ __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, ui
         float4 o;
         o.x = t;
         o.y = __int_as_float(hit ? i1 : -1); o.z = __int_as_float(hit ? i2 : -1); o.w = __int_as_float(hit ? i3 : -1);
-        *(float4*)(a.hits + (a.perm ? (uint64_t)tag : id)) = o;
+        *(float4*)(a.hits + id) = o;
     } else if (MODE == MODE_JOBS) {
         uint4 o0, o1;
         o0.x = __float_as_uint(t);
@@ -378,7 +378,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
-    bool active = false;
+    bool active = false, pend = false;      /* pend: this lane has fetched the index of its next ray but not the ray */
+    uint32_t pendIdx = 0;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;       /* rcpD duplicated into both halves */
     uint32_t cur = 0; int sp = 0;
@@ -416,15 +417,24 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
 
     for (;;) {
         /* ---- refill: idle lanes take ray ids and issue the loads of their rays; the words are used after the step
-                below, so that these loads and the step's record fetch are one wait ---- */
-        uint64_t idleMask = __ballot(!active);
+                below, so that these loads and the step's record fetch are one wait.  With an order to follow, a lane
+                first fetches the index of its ray the same way and the ray a turn later ---- */
+        const bool canTake = !active && !pend;
+        uint64_t idleMask = __ballot(canTake);
         int nIdle = __popcll(idleMask);
         if (nIdle == 64 && pool.exhausted()) break;
         bool fresh = false;
         RayWords w;
+        if (MODE == MODE_RAYS && pend) {        /* the index fetched a turn ago names this lane's next ray */
+            id = pendIdx; pend = false;
+            fresh = issue_ray<MODE>(a, id, w);
+        }
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
-            uint64_t nid = pool.claim(a.fetchCounter, !active, idleMask, nIdle);
-            if (!active && nid != ~0ull) { id = nid; fresh = issue_ray<MODE>(a, id, w); }
+            uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
+            if (canTake && nid != ~0ull) {
+                if (MODE == MODE_RAYS && a.order) { pendIdx = a.order[nid]; pend = true; }     /* used next turn: no wait here */
+                else { id = nid; fresh = issue_ray<MODE>(a, id, w); }
+            }
         }
 #ifdef PT_SYNC_REFILL
         if (fresh) { start_ray(w); fresh = false; }     /* diagnostic: the refill waits for its own loads */
