@@ -74,19 +74,43 @@ __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scan(uint32_t* binCount, 
 
 __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(uint64_t n, const uint16_t* keys, uint32_t* cursor, int nbins, uint32_t* order)
 {
-    __shared__ uint32_t hist[PT_SORT_BINS];       /* first the tile's count per bin, then the next free place in the tile's slice */
-    for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) hist[b] = 0;
+    /* The tile is first ordered inside LDS, then written out in that order: a tile's rays of one bin are one run in the
+       output, so lanes next to each other write indices next to each other. */
+    __shared__ uint32_t hist[PT_SORT_BINS];       /* tile count per bin, then the next free place of the bin in tile order */
+    __shared__ uint32_t gbase[PT_SORT_BINS];      /* place of the tile's slice of the bin in the output, minus the bin's start in tile order */
+    __shared__ uint16_t local[PT_SORT_TILE];      /* local[place in tile order] = index in the tile */
+    __shared__ uint32_t part[PT_SORT_BLOCK];
+    const int t = threadIdx.x, per = PT_SORT_BINS / PT_SORT_BLOCK;
+    for (int b = t; b < PT_SORT_BINS; b += PT_SORT_BLOCK) hist[b] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * PT_SORT_TILE;
-    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += PT_SORT_BLOCK) {
-        const uint64_t i = base + k;
-        if (i < n) atomicAdd(&hist[keys[i]], 1u);
+    const uint32_t count = (uint32_t)((n - base < PT_SORT_TILE) ? n - base : PT_SORT_TILE);
+    for (uint32_t k = t; k < count; k += PT_SORT_BLOCK) atomicAdd(&hist[keys[base + k]], 1u);
+    __syncthreads();
+    /* exclusive scan of the tile histogram: four consecutive bins per thread */
+    uint32_t c[per], s = 0;
+    for (int k = 0; k < per; k++) { c[k] = hist[t * per + k]; s += c[k]; }
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < PT_SORT_BLOCK; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int k = 0; k < per; k++) {
+        const int b = t * per + k;
+        if (c[k]) gbase[b] = atomicAdd(cursor + b, c[k]) - run;
+        hist[b] = run;
+        run += c[k];
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nbins; b += PT_SORT_BLOCK) { uint32_t c = hist[b]; hist[b] = c ? atomicAdd(cursor + b, c) : 0u; }
+    for (uint32_t k = t; k < count; k += PT_SORT_BLOCK) local[atomicAdd(&hist[keys[base + k]], 1u)] = (uint16_t)k;
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < PT_SORT_TILE; k += PT_SORT_BLOCK) {
-        const uint64_t i = base + k;
-        if (i < n) order[atomicAdd(&hist[keys[i]], 1u)] = (uint32_t)i;
+    for (uint32_t pos = t; pos < count; pos += PT_SORT_BLOCK) {
+        const uint32_t k = local[pos];
+        order[gbase[keys[base + k]] + pos] = (uint32_t)(base + k);
     }
+    (void)nbins;
 }
