@@ -341,3 +341,30 @@ def test_cornell_box_512_four_bounces(gpu_ctx, oracle_lib):
     rays = helpers.random_rays(nodes[0]["a"], nodes[0]["b"], 20000, seed=1)
     _, ran = osc.trace(rays, want_ranoff=True)
     assert (ran != 0).mean() > 0.01
+
+
+def test_frames_in_flight_survive_resize_clear_and_speculative(gpu_ctx, oracle_lib, monkey):
+    """The extra frame pipes are rebuilt after pt_resize, a cleared accumulation reseeds exactly the first frame of the
+    next batch (launch.comp:49-50), an empty batch does nothing, and the subgroup-vote build of depth 0 works with
+    frames in flight."""
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 3)
+    mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS
+    for (W, H, NR) in ((96, 64, 3), (128, 72, 2)):
+        osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+        gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 3)
+        c = _consts(monkey, W, H, NR, 1, {})
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_samples(1, 0)
+        assert (gpu_ctx.readback_accumulation() == 0).all()
+        gpu_ctx.render_samples(1, 4, speculative_depth0=True)
+        for frame in range(1, 5):
+            c["frameIndex"] = frame
+            oracle.render_frame(osc, fr, c, subgroup0=64, mode=mode)
+        _compare(gpu_ctx, fr, live_slots_only=True)
+        gpu_ctx.clear_accumulation()
+        fr.clear_accumulation()
+        gpu_ctx.render_samples(5, 5)
+        for frame in range(5, 10):
+            c["frameIndex"] = frame
+            oracle.render_frame(osc, fr, c, mode=mode)
+        _compare(gpu_ctx, fr, live_slots_only=True)
