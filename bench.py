@@ -206,6 +206,10 @@ def main():
             result["extra"]["sponza_stand_in"] = path_tracer_spp(ctx, sridx.shape[0], snodes.shape[0])
         except Exception as e:      # the context lines must not take the headline down
             result["extra"] = {"error": str(e)}
+    if world > 1 and not args.no_extra:
+        extra = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend)
+        if rank == 0:
+            result["extra"] = {"san_miguel_stand_in_partitioned": extra}
     ctx.close()
     if world > 1:
         dist.barrier()
@@ -258,6 +262,57 @@ def path_tracer_spp(ctx, num_triangles, num_nodes):
     rays = int(rc[:2 * NR].sum())
     return {"spp_per_s_1080p": round(nf / dt, 2), "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
             "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1)}
+
+
+def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, backend):
+    """Context number for N > 1: sample-partitioned rendering.  Every rank renders its own block of frame indices at
+    1080p x 8 bounces into its own accumulation buffer (per-frame reseed), then one all-reduce (RCCL) sums the RGBA32F
+    buffers, .w = sample count included.  Every rank takes part in every collective whatever happens to it locally:
+    a rank that fails says so in a flag that is reduced first, and then nobody enters the data all-reduce."""
+    import torch
+    import torch.distributed as dist
+    import pathtracer_amd as pt
+    from pathtracer_amd import core, distributed
+    W, H, NR, nf = 1920, 1080, 8, 24
+    dev = "cuda" if backend == "nccl" else "cpu"
+    ok, err = 1, ""
+    try:
+        ctx.set_option(core.OPT_RESEED, 1)
+        ctx.resize(W, H, NR)
+        ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
+        ctx.render_samples(1 + rank * 3, 3)             # warm-up, also brings the extra frame pipes up
+        ctx.clear_accumulation()
+        ctx.synchronize()
+    except Exception as e:
+        ok, err = 0, str(e)
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"error": err or "another rank failed during set-up"}
+    dist.barrier()
+    t = time.perf_counter()
+    try:
+        ctx.render_samples(1000 + rank * nf, nf)
+        ctx.synchronize()
+        t_render = time.perf_counter() - t
+    except Exception as e:
+        ok, err, t_render = 0, str(e), 0.0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        return {"error": err or "another rank failed while rendering"}
+    distributed.allreduce_accumulation_torch(ctx)       # raises on every rank or on none: same library, same buffer size
+    dt = time.perf_counter() - t
+    tt = torch.tensor([dt, t_render], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt, t_render = float(tt[0].item()), float(tt[1].item())
+    out = {"spp_per_s_1080p": round(world * nf / dt, 2), "frames_per_rank": nf, "bounces": NR, "triangles": int(num_triangles),
+           "render_s": round(t_render, 4), "allreduce_s": round(dt - t_render, 4), "allreduce_bytes": 16 * W * H}
+    if rank == 0:
+        acc = ctx.readback_accumulation()
+        out["samples_per_pixel_after_allreduce"] = [float(acc[..., 3].min()), float(acc[..., 3].max())]
+    ctx.set_option(core.OPT_RESEED, 0)
+    return out
 
 
 if __name__ == "__main__":
