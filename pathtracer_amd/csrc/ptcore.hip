@@ -783,7 +783,8 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
     TraceArgs a; fill_trace_args(ctx, a);
     a.rays = d_rays; a.hits = d_hits; a.count = num_rays; a.countPtr = nullptr; a.fetchCounter = ctx->dFetch;
     /* large batches are first ordered by the cell of the scene box their origin lies in (sort_kernels.h) */
-    const bool sort = ctx->optSortRays == 1 || (ctx->optSortRays == 2 && num_rays >= (1u << 20));
+    const bool sort = ctx->optTraversal != 0 &&        /* the reference-layout kernel takes its rays in batch order */
+                      (ctx->optSortRays == 1 || (ctx->optSortRays == 2 && num_rays >= (1u << 20)));
     if (sort) {
         if (ctx->sortCapacity < num_rays) {
             HIPCHK(hipStreamSynchronize(ctx->stream));
