@@ -368,3 +368,32 @@ def test_frames_in_flight_survive_resize_clear_and_speculative(gpu_ctx, oracle_l
             c["frameIndex"] = frame
             oracle.render_frame(osc, fr, c, mode=mode)
         _compare(gpu_ctx, fr, live_slots_only=True)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_soup_frames_match_oracle(gpu_ctx, oracle_lib, seed):
+    """Whole frames on random triangle soups with random vertex colours, transparent vertices (alpha 0: the refraction
+    branch, trace.comp:136-149) and normals that are neither unit length nor consistent with the winding: every buffer
+    equals the oracle's."""
+    rng = np.random.default_rng(seed)
+    n = 96
+    pos = np.ones((3 * n, 4), np.float32)
+    pos[:, :3] = rng.uniform(-1, 1, (3 * n, 3)).astype(np.float32)
+    pos[:, 1] += 1.0
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    aux = np.zeros(3 * n, dtype=pt.AUX_DT)
+    aux["normal"] = rng.normal(0, 1, (3 * n, 3)).astype(np.float32)
+    aux["color"] = rng.integers(0, 256, (3 * n, 4), dtype=np.uint8)
+    aux["color"][:, 3] = np.where(rng.random(3 * n) < 0.3, 0, 255)
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 1)
+    model = dict(positions=pos, aux=aux, indices=ridx, nodes=nodes)
+    W, H, NR = 96, 64, 5
+    osc, fr = _setup(gpu_ctx, model, W, H, NR)
+    cam = dict(focus_center=(0.0, 1.0, 0.0), orbit_height=1.2, orbit_radius=3.0, orbit_angle=0.3 * seed)
+    for frame in (1, 2, 3):
+        c = _consts(model, W, H, NR, frame, cam)
+        gpu_ctx.set_constants(c)
+        gpu_ctx.render_sample(frame)
+        oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        _compare(gpu_ctx, fr)
+    assert (gpu_ctx.readback_accumulation()[..., :3] > 0).mean() > 0.05
