@@ -46,3 +46,31 @@ def oracle_scene(model, lights=None, blue_noise=None):
 
 def upload(ctx, model, lights=None, blue_noise=None):
     ctx.upload_scene(model["positions"], model["aux"], model["indices"], model["nodes"], lights, blue_noise)
+
+
+def triangle_soup(rng, n, kind):
+    """Random triangle soups that stress the arithmetic: sizes from 2 triangles up, flat axis-aligned triangles (boxes
+    of zero thickness: only the builder's 6e-5 pad, an fp16 subnormal, keeps them open), slivers, shared vertices,
+    and coordinates far from the origin or beyond the fp16 range (the box digest then holds infinities)."""
+    if kind == "unit":
+        v = rng.uniform(-1, 1, (3 * n, 3))
+    elif kind == "flat":
+        v = rng.uniform(-1, 1, (3 * n, 3))
+        axis = rng.integers(0, 3, n)
+        for t in range(n):
+            v[3 * t:3 * t + 3, axis[t]] = np.round(rng.uniform(-1, 1), 2)
+    elif kind == "sliver":
+        a = rng.uniform(-1, 1, (n, 3)); d = rng.normal(0, 1, (n, 3))
+        v = np.stack([a, a + d, a + d * (1 + 1e-4) + rng.normal(0, 1e-5, (n, 3))], 1).reshape(-1, 3)
+    elif kind == "offset":
+        v = rng.uniform(-1, 1, (3 * n, 3)) * 0.25 + np.array([900.0, -350.0, 1200.0])
+    else:   # "huge": extents beyond 65504, the largest fp16
+        v = rng.uniform(-1, 1, (3 * n, 3)) * 2.0e5
+    pos = np.ones((3 * n, 4), np.float32)
+    pos[:, :3] = v.astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    if n > 4:                                   # let some triangles share vertices
+        idx[1, 0] = idx[0, 0]; idx[2, 1] = idx[0, 2]
+    a, b, c = pos[idx[:, 0], :3], pos[idx[:, 1], :3], pos[idx[:, 2], :3]
+    keep = np.linalg.norm(np.cross(b - a, c - a), axis=1) > 0      # zero-area triangles: the documented NaN deviation
+    return pos, np.ascontiguousarray(idx[keep])

@@ -289,3 +289,19 @@ def test_flatten_pass_compact_refuses_a_box_it_cannot_encode(bunny):
     nodes["b"][k] = (4096.0 + 2.0 ** -11 * 3, 1.0, 1.0)
     assert pt.flatten_bvh_compact(nodes, bunny["positions"], bunny["indices"]) is None
     pt.flatten_bvh(nodes, bunny["positions"], bunny["indices"])  # the 64 B pass takes any box
+
+
+@pytest.mark.parametrize("kind", ["unit", "flat", "sliver", "offset", "huge"])
+def test_bvh_builder_bit_identical_on_random_soups(oracle_lib, kind):
+    """The parallel builder against the oracle's restatement of BVH.cpp:83-309 on awkward random inputs: every node
+    byte and the reordered index array are the same."""
+    import helpers
+    import oracle
+    rng = np.random.default_rng(7)
+    for n in (2, 3, 5, 17, 64, 257, 2000):
+        pos, idx = helpers.triangle_soup(rng, n, kind)
+        for threads in (1, 4):
+            nodes, ridx, depth = pt.build_bvh(pos, idx, threads)
+            onodes, oridx, odepth = oracle.build_bvh(pos, idx)
+            assert np.array_equal(nodes.view(np.uint8), onodes.view(np.uint8)), (kind, n, threads)
+            assert np.array_equal(ridx, oridx) and depth == odepth
