@@ -141,11 +141,14 @@ void free_frame(PtContext* c)
     c->rngPipe = c->lastPipe = c->resolvePipe = 0;
 }
 
-/* Launch shape of the persistent traversal kernels.  Batches ordered by origin cell run best with one more workgroup per
- * CU and earlier refills (their lanes share lines, so more of them in flight cost less); both are overridden by
- * PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN. */
-int blocks_per_cu(PtContext* c, bool ordered) { return (ordered && !c->userBlocks) ? 6 : c->optBlocksPerCU; }
-int refill_min(PtContext* c, bool ordered) { return (ordered && !c->userRefill) ? 24 : c->optRefillMin; }
+/* Launch shape of the persistent traversal kernels: workgroups per CU and the number of idle lanes at which a wavefront
+ * refills.  Measured optima differ by use: a batch in the order it was given 5 and 36; a batch ordered by origin cell
+ * 6 and 24 (its lanes share lines, so more of them in flight cost less); the passes of the path tracer 3 and 12
+ * (several of them share the CUs at any time, and their rays are coherent).  PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN
+ * override all three. */
+enum { SHAPE_BATCH = 0, SHAPE_ORDERED_BATCH = 1, SHAPE_FRAME = 2 };
+int blocks_per_cu(PtContext* c, int shape) { static const int d[3] = { 5, 6, 3 }; return c->userBlocks ? c->optBlocksPerCU : d[shape]; }
+int refill_min(PtContext* c, int shape) { static const int d[3] = { 36, 24, 12 }; return c->userRefill ? c->optRefillMin : d[shape]; }
 int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 6 || c->userBlocks ? c->optBlocksPerCU : 6); }   /* sizes the spill areas */
 
 /* Spill areas of the LDS stacks: one per traversal kernel that can be running at a time, that is two per pipe
@@ -185,9 +188,9 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
     a.overflowEntries = ctx->overflowEntries;
-    const bool ordered = a.order != nullptr;
-    dim3 grid(ctx->numCUs * blocks_per_cu(ctx, ordered)), block(PT_BLOCK);
-    a.refillMin = (uint32_t)refill_min(ctx, ordered);
+    const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
+    dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
+    a.refillMin = (uint32_t)refill_min(ctx, shape);
     const int trav = ctx->optTraversal;
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);

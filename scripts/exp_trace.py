@@ -14,8 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--tris", type=int, default=1_000_000)
 ap.add_argument("--rays", type=int, default=1 << 24)
 ap.add_argument("--reps", type=int, default=3)
-ap.add_argument("--blocks", type=str, default="6")
-ap.add_argument("--refill", type=str, default="24")
+ap.add_argument("--blocks", type=str, default="0", help="0 = library default")
+ap.add_argument("--refill", type=str, default="0", help="0 = library default")
 ap.add_argument("--modes", type=str, default="0,1,2")
 ap.add_argument("--chunk", type=str, default="0")
 ap.add_argument("--sort", type=int, default=2)
@@ -60,8 +60,10 @@ for mode in [int(m) for m in args.modes.split(",")]:
             ctx.set_option(core.OPT_SORT_BITS, bits)
             ctx.set_option(core.OPT_CLAIM_CHUNK, chunk)
             ctx.set_option(core.OPT_SORT_RAYS, args.sort)
-            ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
-            ctx.set_option(core.OPT_REFILL_MIN, refill)
+            if blocks:
+                ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
+            if refill:
+                ctx.set_option(core.OPT_REFILL_MIN, refill)
             ms = []
             ctx.synchronize()
             tw = time.perf_counter()
