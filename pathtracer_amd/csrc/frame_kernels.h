@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void k_launch(FrameArgs f)
 }
 
 /* trace.comp:58-233 minus the two walks */
-#define PT_SHADE_BLOCK 1024
+#define PT_SHADE_BLOCK 256
 __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t depthIndex)
 {
     const uint32_t j = blockIdx.x * PT_SHADE_BLOCK + threadIdx.x;
@@ -219,8 +219,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
         }
     }
 
-    /* Counts go to the device counters once per workgroup (sixteen wavefronts): one atomic per wavefront on the same
-     * word serialises in one L2 channel and was the larger part of this kernel's time. */
+    /* Counts go to the device counters once per workgroup: one atomic per wavefront on the same word serialises in one
+     * L2 channel and was the larger part of this kernel's time.  Four wavefronts per workgroup is the measured optimum
+     * for the path tracer: with sixteen the atomics are fewer still, but a workgroup then needs sixteen free wave slots
+     * on one CU at once, which the persistent traversal kernels of the frames in flight rarely leave (201 against
+     * 220 spp/s at 1080p). */
     __shared__ uint32_t shCount[3][PT_SHADE_BLOCK / 64];
     __shared__ uint32_t shBase[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
             for (int k = 0; k < 3; k++) { uint32_t c = shCount[k][w]; shCount[k][w] = tot[k]; tot[k] += c; }
         shBase[0] = (f.fuseCompact && tot[0]) ? atomicAdd(f.ctr + CTR_COMPACT_OUT, tot[0]) : 0u;
         shBase[1] = tot[1] ? atomicAdd(f.shadowCtr, tot[1]) : 0u;
-        if (tot[2]) atomicAdd(f.ctr + CTR_LIVE, tot[2]);
+        if (tot[2] && !f.fuseCompact) atomicAdd(f.ctr + CTR_LIVE, tot[2]);      /* a compacted list holds live jobs only: its length is the count */
     }
     __syncthreads();
 
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
  * over and clears the counters the next depth's closest-hit and shade passes start from. */
 __global__ void k_record_counts(FrameArgs f, uint32_t depthIndex)
 {
-    f.rayCounts[2 * depthIndex] += f.ctr[CTR_LIVE];
+    f.rayCounts[2 * depthIndex] += f.fuseCompact ? f.ctr[CTR_NJOBS] : f.ctr[CTR_LIVE];
     f.rayCounts[2 * depthIndex + 1] += f.shadowCtr[0];
     if (f.fuseCompact) {
         f.ctr[CTR_NJOBS] = f.ctr[CTR_COMPACT_OUT];
