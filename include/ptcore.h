@@ -188,8 +188,12 @@ PT_API void pt_fill_constants(PtShaderConstants* c, uint32_t width, uint32_t hei
                               const float ambient[3]);
 
 /* ------------------------------------------------------------------------------------------
- * Device context.  One context per GPU per process; all work of a context runs in order on
- * one HIP stream, which replaces the Vulkan barriers of PathTracer.cpp:782-818.
+ * Device context.  One context per GPU per process; to the caller all work of a context is
+ * ordered on one HIP stream (pt_stream), which replaces the Vulkan barriers of
+ * PathTracer.cpp:782-818.  pt_render_samples runs frames side by side on further streams of
+ * its own and joins them to that stream before it returns.  Every call makes the context's
+ * device the calling thread's current HIP device.  A context is not thread-safe: calls on one
+ * context must come from one thread at a time; contexts of different devices are independent.
  * ---------------------------------------------------------------------------------------- */
 typedef struct PtContext PtContext;
 

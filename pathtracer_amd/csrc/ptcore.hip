@@ -1,8 +1,11 @@
 /*
  * ptcore.hip — the device context behind include/ptcore.h: owns every buffer the reference binds
  * to its descriptor set (reference PathTracer.cpp:490-502), launches the kernels of
- * trace_kernels.h / frame_kernels.h in order on one HIP stream, and reports failures as status
- * codes.  There is no CPU path: without a gfx950 device pt_ctx_create fails.
+ * trace_kernels.h / frame_kernels.h / sort_kernels.h, and reports failures as status codes.
+ * Every call is ordered on the context's stream as far as the caller can tell; inside
+ * pt_render_samples several frames run side by side on streams of their own and are joined
+ * to that stream before the call returns.  A context is not thread-safe: one thread at a time.
+ * There is no CPU path: without a gfx950 device pt_ctx_create fails.
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -214,6 +217,10 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     return 0;
 }
 
+/* Every entry point that touches the device starts here: allocations go to the current device, and a host thread that
+ * drives several contexts has whichever device it used last. */
+int enter(PtContext* ctx) { HIPCHK(hipSetDevice(ctx->device)); return 0; }
+
 int check_scene(PtContext* ctx) { return ctx->T ? 0 : ctx->fail(-2, "no scene uploaded (call pt_scene_upload first)"); }
 int check_frame(PtContext* ctx)
 {
@@ -251,6 +258,7 @@ int ensure_pipe(PtContext* ctx, int k)
         HIPCHK(hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming));
     }
     if (p.ready) return 0;
+    free_pipe_buffers(p);                                 /* what an earlier attempt that ran out of memory left behind */
     const size_t px = (size_t)ctx->W * ctx->H;
     HIPCHK(hipMalloc((void**)&p.dStack, px * ctx->slots * sizeof(PtRayStackSlot)));
     HIPCHK(hipMalloc((void**)&p.dJobs[0], px * 4));
@@ -347,6 +355,7 @@ PT_API const char* pt_last_error(PtContext* ctx) { return ctx ? ctx->err.c_str()
 PT_API int pt_synchronize(PtContext* ctx)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -391,6 +400,7 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
                            const PtBVHNode* nodes, uint32_t N, const PtLight* lights, uint32_t L, const uint16_t* blue_noise)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!positions || !indices || !nodes || V == 0 || T == 0) return ctx->fail(-1, "pt_scene_upload: null or empty geometry");
     if (N != 2 * T - 1) return ctx->fail(-1, "pt_scene_upload: node count must be 2*T-1");
     for (size_t i = 0; i < 3 * (size_t)T; i++) if (indices[i] >= V) return ctx->fail(-1, "pt_scene_upload: vertex index out of range");
@@ -398,7 +408,6 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
         if (nodes[i].next < 0 || (uint32_t)nodes[i].next >= N || nodes[i].right >= (int32_t)N) return ctx->fail(-1, "pt_scene_upload: node link out of range");
         if (nodes[i].right <= 0 && ((uint32_t)(-nodes[i].right) % 3 != 0 || (uint32_t)(-nodes[i].right) / 3 >= T)) return ctx->fail(-1, "pt_scene_upload: leaf offset out of range");
     }
-    HIPCHK(hipSetDevice(ctx->device));
     if (int rc = sync_all(ctx)) return rc;
     free_scene(ctx);
 
@@ -475,9 +484,9 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
 PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (W == 0 || H == 0 || max_slots == 0) return ctx->fail(-1, "pt_resize: zero dimension");
     if ((uint64_t)W * H * max_slots >= 0xFFFFFFFFull) return ctx->fail(-1, "pt_resize: W*H*slots must fit a 32-bit slot index");
-    HIPCHK(hipSetDevice(ctx->device));
     if (int rc = sync_all(ctx)) return rc;
     free_frame(ctx);
     size_t px = (size_t)W * H;
@@ -505,6 +514,7 @@ PT_API int pt_set_constants(PtContext* ctx, const PtShaderConstants* c)
 PT_API int pt_clear_accumulation(PtContext* ctx)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     HIPCHK(hipMemsetAsync(ctx->dAccum, 0, (size_t)ctx->W * ctx->H * 16, ctx->stream));
     ctx->accumEmpty = true;
@@ -531,6 +541,7 @@ static int launch_on(PtContext* ctx, FramePipe& p)
 PT_API int pt_launch(PtContext* ctx)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     return launch_on(ctx, ctx->pipe[0]);
 }
@@ -598,6 +609,7 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
 PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_trace: scene was uploaded without vertex attributes or lights");
     if (depth >= ctx->slots) return ctx->fail(-1, "pt_trace: depth exceeds the allocated slots");
@@ -608,6 +620,7 @@ PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
 PT_API int pt_compact(PtContext* ctx)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     FramePipe& p = ctx->pipe[0];
     HIPCHK(hipMemsetAsync(p.dCtr + CTR_COMPACT_OUT, 0, 4, p.stream));
@@ -639,6 +652,7 @@ static int resolve_on(PtContext* ctx, FramePipe& p)
 PT_API int pt_resolve_accumulate(PtContext* ctx)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     return resolve_on(ctx, ctx->pipe[0]);
 }
@@ -656,6 +670,7 @@ static int frame_on(PtContext* ctx, FramePipe& p, uint32_t frame_index, int spec
 PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, int speculative_depth0, uint64_t* ray_counts)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_render_sample: scene was uploaded without vertex attributes or lights");
     if (speculative_depth0 && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_render_sample: the speculative build needs W and H to be multiples of 8");
@@ -701,6 +716,7 @@ PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculativ
 PT_API int pt_readback_current(PtContext* ctx, uint16_t* rgba16f)
 {
     if (!ctx || !rgba16f) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     HIPCHK(hipMemcpyAsync(rgba16f, ctx->dCurrent, (size_t)ctx->W * ctx->H * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -709,6 +725,7 @@ PT_API int pt_readback_current(PtContext* ctx, uint16_t* rgba16f)
 PT_API int pt_readback_accumulation(PtContext* ctx, float* rgba32f)
 {
     if (!ctx || !rgba32f) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     HIPCHK(hipMemcpyAsync(rgba32f, ctx->dAccum, (size_t)ctx->W * ctx->H * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -717,6 +734,7 @@ PT_API int pt_readback_accumulation(PtContext* ctx, float* rgba32f)
 PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob* jobs)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
     FramePipe& p = ctx->pipe[ctx->lastPipe];           /* the stack and job list of the most recent frame */
@@ -728,6 +746,7 @@ PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob*
 PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const PtRayJob* jobs)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
     FramePipe& p = ctx->pipe[0];                        /* the dispatch-site calls that follow work on pipe 0 */
@@ -757,6 +776,7 @@ PT_API int pt_dump_current(PtContext* ctx, const char* dir, uint32_t index)
 PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     if (!rgb32f && !rgba8) return 0;
     const size_t px = (size_t)ctx->W * ctx->H;
@@ -776,6 +796,7 @@ PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8)
 PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits, uint64_t* stats)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_scene(ctx)) return rc;
     if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays: null buffer");
     /* the id counter is 32 bits wide and every wavefront may overshoot the count by one chunk */
@@ -828,6 +849,7 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
 PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t n, int any_hit, PtHit* hits, uint64_t* stats)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!rays || !hits) return ctx->fail(-1, "pt_trace_rays_host: null buffer");
     if (n == 0) return 0;
     PtRay* dr = nullptr; PtHit* dh = nullptr;
@@ -846,6 +868,7 @@ PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t n, int
 PT_API int pt_generate_rays(PtContext* ctx, uint64_t seed, uint64_t first, uint64_t n, PtRay* d_rays)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (int rc = check_scene(ctx)) return rc;
     if (!d_rays) return ctx->fail(-1, "pt_generate_rays: null buffer");
     if (n == 0) return 0;
@@ -859,7 +882,7 @@ PT_API int pt_generate_rays(PtContext* ctx, uint64_t seed, uint64_t first, uint6
 
 PT_API void* pt_device_alloc(PtContext* ctx, size_t bytes)
 {
-    if (!ctx) return nullptr;
+    if (!ctx || enter(ctx)) return nullptr;
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) { ctx->fail(-10, std::string("hipMalloc: ") + hipGetErrorString(e)); return nullptr; }
@@ -868,6 +891,7 @@ PT_API void* pt_device_alloc(PtContext* ctx, size_t bytes)
 PT_API int pt_device_free(PtContext* ctx, void* p)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipFree(p));
     return 0;
@@ -875,6 +899,7 @@ PT_API int pt_device_free(PtContext* ctx, void* p)
 PT_API int pt_copy_to_host(PtContext* ctx, void* dst, const void* d_src, size_t bytes)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -882,6 +907,7 @@ PT_API int pt_copy_to_host(PtContext* ctx, void* dst, const void* d_src, size_t 
 PT_API int pt_copy_to_device(PtContext* ctx, void* d_dst, const void* src, size_t bytes)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     HIPCHK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -928,6 +954,7 @@ PT_API int pt_comm_init(PtContext* ctx, int rank, int num_ranks, const uint8_t u
 PT_API int pt_allreduce_accumulation(PtContext* ctx)
 {
     if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
     if (!ctx->comm) return ctx->fail(-2, "pt_allreduce_accumulation: call pt_comm_init first");
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     /* one sum over RGBA32F: .w carries the sample count and sums with the radiance */
