@@ -38,6 +38,13 @@ for bits in (1, 2, 3, 4, 5):
     q = np.clip(((rays["o"] - lo) / (hi - lo) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
     key = part1by2(q[:, 0]) | (part1by2(q[:, 1]) << 1) | (part1by2(q[:, 2]) << 2)
     run(f"sorted by origin cell, {bits} bits/axis", rays[np.argsort(key, kind="stable")])
-    continue
+    if bits < 3:
+        continue
     octant = ((rays["d"][:, 0] > 0).astype(np.uint64) | ((rays["d"][:, 1] > 0).astype(np.uint64) << 1) | ((rays["d"][:, 2] > 0).astype(np.uint64) << 2))
     run(f"  + direction octant", rays[np.argsort((key << 3) | octant, kind="stable")])
+    run(f"  direction octant first, then cell", rays[np.argsort((octant << np.uint64(3 * bits)) | key, kind="stable")])
+    # direction quantised finer: 6 faces x 2x2 of the direction cube (24 classes)
+    d = rays["d"]; ax = np.argmax(np.abs(d), axis=1); sgn = (np.take_along_axis(d, ax[:, None], 1)[:, 0] > 0)
+    u = np.take_along_axis(d, ((ax + 1) % 3)[:, None], 1)[:, 0] > 0; v = np.take_along_axis(d, ((ax + 2) % 3)[:, None], 1)[:, 0] > 0
+    dclass = (ax.astype(np.uint64) * 2 + sgn) * 4 + u * 2 + v
+    run(f"  + 24 direction classes", rays[np.argsort((key << np.uint64(5)) | dclass.astype(np.uint64), kind="stable")])
