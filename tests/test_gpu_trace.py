@@ -282,3 +282,42 @@ def test_random_triangle_soups_exact(gpu_ctx, oracle_lib, kind):
         near = gpu_ctx.trace_rays(rays)
         assert np.array_equal(near["i1"] >= 0, hits["i1"] >= 0)
     gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+
+
+def test_deep_stacks_spill_past_the_lds_part(gpu_ctx, oracle_lib):
+    """A pile of 30 000 large parallel triangles: a ray through the corner their boxes cover and they do not passes
+    both children's boxes at every node, so a walk has as many siblings pending as the tree is deep (15 or more),
+    past the twelve entries a lane's stack has in LDS.  Results must still be the oracle's bit for bit."""
+    n = 30_000
+    z = np.linspace(-1.0, 1.0, n, dtype=np.float32)
+    pos = np.ones((3 * n, 4), np.float32)
+    pos[0::3, :3] = np.stack([np.full(n, -1.0), np.full(n, -1.0), z], 1)
+    pos[1::3, :3] = np.stack([np.full(n, 1.0), np.full(n, -1.0), z], 1)
+    pos[2::3, :3] = np.stack([np.full(n, -1.0), np.full(n, 1.0), z], 1)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    aux = np.zeros(pos.shape[0], dtype=pt.AUX_DT)
+    nodes, ridx, depth = pt.build_bvh(pos, idx, 4)
+    assert depth > 13
+    model = dict(positions=pos, aux=aux, indices=ridx, nodes=nodes)
+    helpers.upload(gpu_ctx, model)
+    osc = helpers.oracle_scene(model)
+    rng = np.random.default_rng(11)
+    m = 1024
+    rays = np.zeros(m, dtype=pt.RAY_DT)
+    # half the rays run along z through the empty corner (x + y > 0), half through the triangles
+    xy = rng.uniform(0.05, 0.95, (m, 2)).astype(np.float32)
+    xy[m // 2:] = -xy[m // 2:]
+    rays["o"] = np.concatenate([xy, np.full((m, 1), -1.5, np.float32)], 1)
+    d = np.concatenate([rng.normal(0, 0.02, (m, 2)), np.ones((m, 1))], 1)
+    rays["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays["min_t"], rays["max_t"] = 0.001, 1e5
+    try:
+        for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_REFERENCE_LAYOUT):
+            _check(gpu_ctx, model, osc, rays, False, trav)
+            _check(gpu_ctx, model, osc, rays, True, trav)
+        _check(gpu_ctx, model, osc, rays, False, core.TRAVERSAL_FLAT_ORDERED, exact=False)
+        _check(gpu_ctx, model, osc, rays, True, core.TRAVERSAL_FLAT_ORDERED)
+        st = gpu_ctx.trace_rays(rays[: m // 2], want_stats=True)[1]
+        assert st[0] / (m // 2) > 2 * n * 0.9          # the corner rays really test nearly every box
+    finally:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
