@@ -397,3 +397,35 @@ def test_random_soup_frames_match_oracle(gpu_ctx, oracle_lib, seed):
         oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
         _compare(gpu_ctx, fr)
     assert (gpu_ctx.readback_accumulation()[..., :3] > 0).mean() > 0.05
+
+
+def test_two_contexts_and_scene_swap(oracle_lib, monkey, bunny):
+    """Two contexts on one device queue frames alternately, and one of them is given another scene half way: each
+    context's buffers stay the oracle's for its own scene, nothing leaks from one to the other."""
+    W, H, NR = 80, 56, 3
+    a, b = pt.PathTracer(0), pt.PathTracer(0)
+    try:
+        osc_a, fr_a = _setup(a, monkey, W, H, NR)
+        osc_b, fr_b = _setup(b, bunny, W, H, NR)
+        for frame in (1, 2):
+            for ctx, osc, fr, model, cam in ((a, osc_a, fr_a, monkey, {}), (b, osc_b, fr_b, bunny, BUNNY_CAM)):
+                c = _consts(model, W, H, NR, frame, cam)
+                ctx.set_constants(c)
+                ctx.render_samples(frame, 1)               # queued, not waited for
+                oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        _compare(a, fr_a)
+        _compare(b, fr_b)
+        # context a changes scene (frame resources stay): a fresh accumulation, the new scene's images
+        helpers.upload(a, bunny, pt.default_lights(), pt.load_blue_noise())
+        a.clear_accumulation()
+        fr_a2 = oracle.Frame(W, H, NR)
+        fr_a2.stack[:] = fr_a.stack                        # the ray stack keeps what the last frame left (RNG states)
+        for frame in (3, 4):
+            c = _consts(bunny, W, H, NR, frame, BUNNY_CAM)
+            a.set_constants(c)
+            a.render_samples(frame, 1)
+            oracle.render_frame(osc_b, fr_a2, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        _compare(a, fr_a2)
+        _compare(b, fr_b)                                  # untouched by all that
+    finally:
+        a.close(); b.close()
