@@ -206,6 +206,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         try:
             result["extra"] = {"san_miguel_stand_in": path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0])}
+            result["extra"]["san_miguel_stand_in_4k"] = path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 12)
             spos, saux, sidx = pt.scenes.sponza_like()
             snodes, sridx, _ = pt.build_bvh(spos, sidx, threads)
             ctx.upload_scene(spos, saux, sridx, snodes, pt.default_lights(), pt.load_blue_noise())
@@ -214,8 +215,9 @@ def main():
             result["extra"] = {"error": str(e)}
     if world > 1 and not args.no_extra:
         extra = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend)
+        extra4k = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend, 3840, 2160, 8)
         if rank == 0:
-            result["extra"] = {"san_miguel_stand_in_partitioned": extra}
+            result["extra"] = {"san_miguel_stand_in_partitioned": extra, "san_miguel_stand_in_partitioned_4k": extra4k}
     ctx.close()
     if world > 1:
         dist.barrier()
@@ -250,36 +252,36 @@ def cpu_baseline(pos, aux, ridx, nodes, d_rays, budget_s):
                       f"(clang++ -O3, {cores} threads)"}
 
 
-def path_tracer_spp(ctx, num_triangles, num_nodes):
-    """Context number: samples per pixel per second of the wavefront path tracer at 1080p, 8 bounces with next-event
-    estimation, on the scene the context holds (BASELINE configs[2] shape); frames in flight at the library default."""
+def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=30):
+    """Context number: samples per pixel per second of the wavefront path tracer at 1080p (or the size given), 8 bounces
+    with next-event estimation, on the scene the context holds (BASELINE configs[2] shape); frames in flight at the
+    library default."""
     import pathtracer_amd as pt
-    W, H, NR = 1920, 1080, 8
+    NR = 8
     ctx.resize(W, H, NR)
     ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
     ctx.render_samples(1, 3)
     ctx.synchronize()
-    nf = 30
     t = time.perf_counter()
     ctx.render_samples(4, nf)
     ctx.synchronize()
     dt = time.perf_counter() - t
     rc = ctx.render_sample(4 + nf, want_ray_counts=True)
     rays = int(rc[:2 * NR].sum())
-    return {"spp_per_s_1080p": round(nf / dt, 2), "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
+    return {f"spp_per_s_{H}p": round(nf / dt, 2), "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
             "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1)}
 
 
-def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, backend):
+def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, backend, W=1920, H=1080, nf=24):
     """Context number for N > 1: sample-partitioned rendering.  Every rank renders its own block of frame indices at
-    1080p x 8 bounces into its own accumulation buffer (per-frame reseed), then one all-reduce (RCCL) sums the RGBA32F
+    1080p (or the size given; 3840 x 2160 is BASELINE configs[3]) x 8 bounces into its own accumulation buffer (per-frame reseed), then one all-reduce (RCCL) sums the RGBA32F
     buffers, .w = sample count included.  Every rank takes part in every collective whatever happens to it locally:
     a rank that fails says so in a flag that is reduced first, and then nobody enters the data all-reduce."""
     import torch
     import torch.distributed as dist
     import pathtracer_amd as pt
     from pathtracer_amd import core, distributed
-    W, H, NR, nf = 1920, 1080, 8, 24
+    NR = 8
     dev = "cuda" if backend == "nccl" else "cpu"
     ok, err = 1, ""
     try:
@@ -312,7 +314,7 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
     tt = torch.tensor([dt, t_render], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, t_render = float(tt[0].item()), float(tt[1].item())
-    out = {"spp_per_s_1080p": round(world * nf / dt, 2), "frames_per_rank": nf, "bounces": NR, "triangles": int(num_triangles),
+    out = {f"spp_per_s_{H}p": round(world * nf / dt, 2), "frames_per_rank": nf, "bounces": NR, "triangles": int(num_triangles),
            "render_s": round(t_render, 4), "allreduce_s": round(dt - t_render, 4), "allreduce_bytes": 16 * W * H}
     if rank == 0:
         acc = ctx.readback_accumulation()
