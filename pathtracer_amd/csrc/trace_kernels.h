@@ -467,6 +467,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         { unsigned long long am = __ballot(true); if (lane == __ffsll(am) - 1) { tFetch += tb_ - ta; nIter++; nLaneSteps += __popcll(am); } }
 #endif
         if (COUNT) nRec++;
+#ifdef PT_EXPERIMENT_EXTRA_VALU
+        {   /* diagnostic: how much does the step's time depend on its vector instruction count? */
+            float dummy = __uint_as_float(q0.x);
+#pragma unroll
+            for (int k = 0; k < PT_EXPERIMENT_EXTRA_VALU; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
+            asm volatile("" :: "v"(dummy));
+        }
+#endif
 #ifdef PT_EXPERIMENT_SAMELINE
         /* diagnostic: the box-test counter counts steps whose record lies in the 128 B line of the previous step's */
         if (COUNT) { if ((off >> 7) == prevLine) nBox++; prevLine = off >> 7; }
