@@ -287,7 +287,7 @@ PT_API void* pt_accumulation_device_ptr(PtContext* ctx);           /* 4 floats x
  * staging buffer it copied to a swapchain cycle earlier (:849 runs before :850 records the copy), so its
  * file f holds the image of frame f - framesInFlight; here <index> is whatever the caller passes.
  * Host-only calls return -1 bad argument, -4 file I/O, -5 zlib, -6 malformed size file or stream length,
- * -7 destination too small. */
+ * -7 destination too small, -8 out of host memory. */
 PT_API int pt_dump_current(PtContext* ctx, const char* dir, uint32_t index);
 PT_API int pt_frame_dump_write(const char* dir, uint32_t index, uint32_t width, uint32_t height,
                                const uint16_t* rgba16f);

@@ -22,6 +22,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -87,9 +89,11 @@ struct Builder {
         int nt = std::min<uint32_t>(nthreads, std::max<uint32_t>(1, n / 4096));
         if (nt <= 1) { f(0, 0, n); return; }
         std::vector<std::thread> th;
+        th.reserve(nt);
         for (int t = 0; t < nt; t++) {
             uint32_t lo = (uint64_t)n * t / nt, hi = (uint64_t)n * (t + 1) / nt;
-            th.emplace_back([=, &f] { f(t, lo, hi); });
+            /* a thread the system refuses to start: its slice runs here instead (the slices do not allocate) */
+            try { th.emplace_back([=, &f] { f(t, lo, hi); }); } catch (const std::system_error&) { f(t, lo, hi); }
         }
         for (auto& t : th) t.join();
     }
@@ -271,27 +275,35 @@ struct Builder {
         }
         std::sort(small.begin(), small.end(), [](const Sub& a, const Sub& b) { return (a.e - a.s) > (b.e - b.s); });
         std::atomic<size_t> cursor{0};
+        std::atomic<bool> failed{false};
         auto worker = [&] {
-            std::vector<Sub> st;
-            std::vector<uint32_t> tl;
-            for (;;) {
-                size_t i = cursor.fetch_add(1);
-                if (i >= small.size()) break;
-                st.push_back(small[i]);
-                while (!st.empty()) {
-                    Sub t = st.back(); st.pop_back();
-                    Sub l, r;
-                    if (process<false>(t, l, r, tl)) { st.push_back(r); st.push_back(l); }
+            try {
+                std::vector<Sub> st;
+                std::vector<uint32_t> tl;
+                for (;;) {
+                    size_t i = cursor.fetch_add(1);
+                    if (i >= small.size() || failed.load()) break;
+                    st.push_back(small[i]);
+                    while (!st.empty()) {
+                        Sub t = st.back(); st.pop_back();
+                        Sub l, r;
+                        if (process<false>(t, l, r, tl)) { st.push_back(r); st.push_back(l); }
+                    }
                 }
-            }
+            } catch (...) { failed.store(true); }      /* out of memory in a worker: reported by the caller's thread */
         };
         int nt = (int)std::min<size_t>(nthreads, small.size());
         if (nt <= 1) worker();
         else {
             std::vector<std::thread> th;
-            for (int i = 0; i < nt; i++) th.emplace_back(worker);
+            th.reserve(nt);
+            for (int i = 0; i + 1 < nt; i++) {
+                try { th.emplace_back(worker); } catch (const std::system_error&) { break; }      /* fewer threads than asked for */
+            }
+            worker();                                   /* this thread helps; with no thread started it does it all */
             for (auto& t : th) t.join();
         }
+        if (failed.load()) throw std::bad_alloc();
     }
 };
 
@@ -308,20 +320,25 @@ extern "C" PT_API int pt_build_bvh(const float* positions, uint32_t num_vertices
     for (size_t i = 0; i < 3 * (size_t)num_triangles; i++)
         if (indices[i] >= num_vertices) { set_err(err, err_len, "pt_build_bvh: vertex index out of range"); return -2; }
 
-    Builder b;
-    b.pos4 = positions; b.idxIn = indices; b.T = num_triangles; b.nodes = nodes;
-    b.nthreads = num_threads > 0 ? num_threads : (int)std::thread::hardware_concurrency();
-    if (b.nthreads < 1) b.nthreads = 1;
-    if (b.nthreads > 256) b.nthreads = 256;
-    b.run();
+    try {
+        Builder b;
+        b.pos4 = positions; b.idxIn = indices; b.T = num_triangles; b.nodes = nodes;
+        b.nthreads = num_threads > 0 ? num_threads : (int)std::thread::hardware_concurrency();
+        if (b.nthreads < 1) b.nthreads = 1;
+        if (b.nthreads > 256) b.nthreads = 256;
+        b.run();
 
-    /* reorder the index triplets as the reference's in-place partitions leave them (BVH.cpp:257-267) */
-    std::vector<uint32_t> out(3 * (size_t)num_triangles);
-    for (size_t k = 0; k < num_triangles; k++) {
-        size_t t = b.order[k];
-        out[3 * k] = indices[3 * t]; out[3 * k + 1] = indices[3 * t + 1]; out[3 * k + 2] = indices[3 * t + 2];
+        /* reorder the index triplets as the reference's in-place partitions leave them (BVH.cpp:257-267) */
+        std::vector<uint32_t> out(3 * (size_t)num_triangles);
+        for (size_t k = 0; k < num_triangles; k++) {
+            size_t t = b.order[k];
+            out[3 * k] = indices[3 * t]; out[3 * k + 1] = indices[3 * t + 1]; out[3 * k + 2] = indices[3 * t + 2];
+        }
+        memcpy(indices, out.data(), out.size() * 4);
+        if (max_depth) *max_depth = b.maxDepth.load();
+    } catch (...) {      /* nothing may unwind through the C boundary; nodes and indices are then unspecified */
+        set_err(err, err_len, "pt_build_bvh: out of memory");
+        return -3;
     }
-    memcpy(indices, out.data(), out.size() * 4);
-    if (max_depth) *max_depth = b.maxDepth.load();
     return 0;
 }

@@ -49,8 +49,9 @@ bool read_all(const std::string& path, std::vector<unsigned char>& out)
 
 extern "C" {
 
+/* Function try blocks: an allocation failure comes back as -8, nothing unwinds through the C boundary. */
 PT_API int pt_frame_dump_write(const char* dir, uint32_t index, uint32_t width, uint32_t height, const uint16_t* rgba16f)
-{
+try {
     if (!rgba16f || !width || !height) return -1;
     const uint64_t bytes = (uint64_t)width * height * 8;
     if (bytes > 0xFFFFFFFFull) return -1;                                        /* the reference's size is a uint32 (PathTracer.cpp:848) */
@@ -63,11 +64,11 @@ PT_API int pt_frame_dump_write(const char* dir, uint32_t index, uint32_t width, 
     int n = snprintf(txt, sizeof txt, "%u,%u\n", width, height);                 /* :198-202 */
     if (!write_all(path + ".txt", txt, (size_t)n)) return -4;
     return 0;
-}
+} catch (...) { return -8; }
 
 PT_API int pt_frame_dump_read(const char* dir, uint32_t index, uint32_t* width, uint32_t* height, uint16_t* rgba16f,
                               uint64_t capacity_texels)
-{
+try {
     if (!width || !height) return -1;
     const std::string path = dump_path(dir, index);
     std::vector<unsigned char> txt;
@@ -86,15 +87,15 @@ PT_API int pt_frame_dump_read(const char* dir, uint32_t index, uint32_t* width, 
     if (rc != Z_OK) return -5;
     if ((uint64_t)got != texels * 8) return -6;
     return 0;
-}
+} catch (...) { return -8; }
 
 PT_API int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8)
-{
+try {
     if (!path || !rgba8 || !width || !height) return -1;
+    std::vector<unsigned char> row((size_t)width * 3);
     FILE* f = fopen(path, "wb");
     if (!f) return -4;
     fprintf(f, "P6\n%u %u\n255\n", width, height);
-    std::vector<unsigned char> row((size_t)width * 3);
     bool ok = true;
     for (uint32_t y = 0; y < height && ok; y++) {
         const uint8_t* s = rgba8 + (size_t)y * width * 4;
@@ -102,6 +103,6 @@ PT_API int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const
         ok = fwrite(row.data(), 1, row.size(), f) == row.size();
     }
     return (fclose(f) == 0 && ok) ? 0 : -4;
-}
+} catch (...) { return -8; }
 
 }  // extern "C"

@@ -131,8 +131,9 @@ struct Reader {
         if (ascii) {
             char tok[64];
             if (fscanf(f, "%63s", tok) != 1) return false;
-            v = strtod(tok, nullptr);
-            return true;
+            char* end = nullptr;
+            v = strtod(tok, &end);
+            return end != tok && *end == '\0';                  /* a token that is not a number ends the read */
         }
         unsigned char buf[8];
         size_t n = type_size(t);
@@ -144,8 +145,8 @@ struct Reader {
 
 }  // namespace
 
-extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint32_t* num_triangles,
-                                  float* positions, PtVertexAux* aux, uint32_t* indices, char* err, size_t err_len)
+static int ply_load(const char* path, uint32_t* num_vertices, uint32_t* num_triangles,
+                    float* positions, PtVertexAux* aux, uint32_t* indices, char* err, size_t err_len)
 {
     auto bail = [&](const std::string& m) { if (err && err_len) snprintf(err, err_len, "pt_ply_load: %s", m.c_str()); return -1; };
     if (!path) return bail("null path");
@@ -153,8 +154,15 @@ extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint
     if (!r.open(path)) return bail(r.error);
 
     uint64_t nv = 0, nt = 0;
+    bool haveVertices = false;
+    auto to_u8 = [](double d) { return (uint8_t)(d >= 255.0 ? 255.0 : d >= 0.0 ? d : 0.0); };      /* NaN -> 0 */
     for (const Element& e : r.elements) {
+        if (e.props.empty() && e.name != "vertex") continue;      /* nothing to read per entry, whatever the count says */
         if (e.name == "vertex") {
+            /* a second vertex element would be counted by the sizing call as the only one and written over the first */
+            if (haveVertices) return bail("more than one vertex element");
+            haveVertices = true;
+            if (e.count > 0xFFFFFFFFull) return bail("model too large");
             int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, ir = -1, ig = -1, ib = -1, ia = -1;
             for (size_t k = 0; k < e.props.size(); k++) {
                 const Prop& p = e.props[k];
@@ -176,8 +184,8 @@ extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint
                 if (aux) {
                     PtVertexAux& a = aux[v];
                     a.normal[0] = inx >= 0 ? (float)row[inx] : 0.0f; a.normal[1] = iny >= 0 ? (float)row[iny] : 0.0f; a.normal[2] = inz >= 0 ? (float)row[inz] : 0.0f;
-                    a.color[0] = ir >= 0 ? (uint8_t)row[ir] : 255; a.color[1] = ig >= 0 ? (uint8_t)row[ig] : 255;
-                    a.color[2] = ib >= 0 ? (uint8_t)row[ib] : 255; a.color[3] = ia >= 0 ? (uint8_t)row[ia] : 255;
+                    a.color[0] = ir >= 0 ? to_u8(row[ir]) : 255; a.color[1] = ig >= 0 ? to_u8(row[ig]) : 255;
+                    a.color[2] = ib >= 0 ? to_u8(row[ib]) : 255; a.color[3] = ia >= 0 ? to_u8(row[ia]) : 255;
                 }
             }
             nv = e.count;
@@ -188,9 +196,15 @@ extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint
                     if (!p.list) { double d; if (!r.next_number(p.type, d)) return bail("truncated face data"); continue; }
                     double cnt;
                     if (!r.next_number(p.countType, cnt)) return bail("truncated face data");
+                    if (!(cnt >= 0.0 && cnt <= 65535.0)) return bail("bad list length in face data");
                     size_t n = (size_t)cnt;
                     poly.resize(n);
-                    for (size_t k = 0; k < n; k++) { double d; if (!r.next_number(p.type, d)) return bail("truncated face data"); poly[k] = (uint32_t)d; }
+                    for (size_t k = 0; k < n; k++) {
+                        double d;
+                        if (!r.next_number(p.type, d)) return bail("truncated face data");
+                        if (!(d >= 0.0 && d <= 4294967295.0)) return bail("face refers to a missing vertex");
+                        poly[k] = (uint32_t)d;
+                    }
                     if (p.name != "vertex_indices" && p.name != "vertex_index") continue;
                     for (size_t k = 1; k + 1 < n; k++) {
                         if (indices) { indices[3 * nt] = poly[0]; indices[3 * nt + 1] = poly[k]; indices[3 * nt + 2] = poly[k + 1]; }
@@ -205,6 +219,7 @@ extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint
                     double d;
                     if (p.list) {
                         if (!r.next_number(p.countType, d)) return bail("truncated data");
+                        if (!(d >= 0.0 && d <= 4294967295.0)) return bail("bad list length");
                         for (size_t k = 0, n = (size_t)d; k < n; k++) if (!r.next_number(p.type, d)) return bail("truncated data");
                     } else if (!r.next_number(p.type, d)) return bail("truncated data");
                 }
@@ -216,4 +231,15 @@ extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint
     if (num_vertices) *num_vertices = (uint32_t)nv;
     if (num_triangles) *num_triangles = (uint32_t)nt;
     return 0;
+}
+
+extern "C" PT_API int pt_ply_load(const char* path, uint32_t* num_vertices, uint32_t* num_triangles,
+                                  float* positions, PtVertexAux* aux, uint32_t* indices, char* err, size_t err_len)
+{
+    try {
+        return ply_load(path, num_vertices, num_triangles, positions, aux, indices, err, err_len);
+    } catch (...) {      /* out of memory while reading: nothing may unwind through the C boundary */
+        if (err && err_len) snprintf(err, err_len, "pt_ply_load: out of memory");
+        return -1;
+    }
 }

@@ -398,7 +398,7 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
 
 PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, const PtVertexAux* aux, const uint32_t* indices, uint32_t T,
                            const PtBVHNode* nodes, uint32_t N, const PtLight* lights, uint32_t L, const uint16_t* blue_noise)
-{
+try {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
     if (!positions || !indices || !nodes || V == 0 || T == 0) return ctx->fail(-1, "pt_scene_upload: null or empty geometry");
@@ -479,7 +479,7 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
     }
     ctx->V = V; ctx->T = T; ctx->N = N; ctx->L = (lights && L) ? L : 0;
     return ensure_overflow(ctx);
-}
+} catch (...) { return ctx->fail(-11, "pt_scene_upload: out of host memory"); }
 
 PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
 {
@@ -668,7 +668,7 @@ static int frame_on(PtContext* ctx, FramePipe& p, uint32_t frame_index, int spec
 }
 
 PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, int speculative_depth0, uint64_t* ray_counts)
-{
+try {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
@@ -706,7 +706,7 @@ PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_
         }
     }
     return 0;
-}
+} catch (...) { return ctx->fail(-11, "pt_render_samples: out of host memory"); }
 
 PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculative_depth0, uint64_t* ray_counts)
 {
@@ -763,7 +763,7 @@ PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const
 PT_API void* pt_accumulation_device_ptr(PtContext* ctx) { return ctx ? (void*)ctx->dAccum : nullptr; }
 
 PT_API int pt_dump_current(PtContext* ctx, const char* dir, uint32_t index)
-{
+try {
     if (!ctx) return -1;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     std::vector<uint16_t> img((size_t)ctx->W * ctx->H * 4);
@@ -771,7 +771,7 @@ PT_API int pt_dump_current(PtContext* ctx, const char* dir, uint32_t index)
     int rc = pt_frame_dump_write(dir, index, ctx->W, ctx->H, img.data());
     if (rc) return ctx->fail(rc, std::string("pt_dump_current: cannot write the dump pair under ") + (dir ? dir : "."));
     return 0;
-}
+} catch (...) { return ctx->fail(-11, "pt_dump_current: out of host memory"); }
 
 PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8)
 {

@@ -38,7 +38,7 @@ void set_err(char* err, size_t n, const char* msg) { if (err && n) snprintf(err,
 extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
                                      uint32_t num_triangles, PtNode2* nodes2, PtTri* tris, float* root_box, uint32_t* max_stack,
                                      char* err, size_t err_len)
-{
+try {
     if (!nodes || !positions || !indices || !tris || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh: null argument"); return -1; }
     if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
 
@@ -98,7 +98,7 @@ extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
         *max_stack = deepest;
     }
     return 0;
-}
+} catch (...) { set_err(err, err_len, "pt_flatten_bvh: out of memory"); return -4; }
 
 /* Shared by both flattening passes: rank of every reference node among the interior nodes (pre-order) or, for a leaf,
  * its triangle index; returns 0 or an error code with a message. */
@@ -137,7 +137,7 @@ static uint32_t tree_depth(const PtBVHNode* nodes)
 extern "C" PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
                                              uint32_t num_triangles, PtNode2c* nodes2, PtTriC* tris, uint32_t* leaf_ref, float* root_box,
                                              uint32_t* max_stack, char* err, size_t err_len)
-{
+try {
     if (!nodes || !positions || !indices || !tris || !leaf_ref || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh_compact: null argument"); return -1; }
     std::vector<uint32_t> rank;
     if (int rc = rank_nodes(nodes, num_nodes, num_triangles, rank, err, err_len)) return rc;
@@ -178,7 +178,7 @@ extern "C" PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t nu
     if (root_box) { for (int k = 0; k < 3; k++) { root_box[k] = nodes[0].a[k]; root_box[3 + k] = nodes[0].b[k]; } }
     if (max_stack) *max_stack = tree_depth(nodes);
     return 0;
-}
+} catch (...) { set_err(err, err_len, "pt_flatten_bvh_compact: out of memory"); return -4; }
 
 /* ------------------------------------------------------------------------------------------
  * Constants block — the values PathTracer.cpp:731-750 writes: glm::lookAt (right-handed),

@@ -77,6 +77,50 @@ def test_ply_reader_ascii_and_errors(tmp_path):
         pt.load_ply(str(bad))
 
 
+def test_ply_reader_refuses_hostile_files(tmp_path):
+    """Files a fuzzer made the reader trip over once: each must come back as an error (or load), never as a crash, a
+    hang or a buffer written past its end."""
+    head = ("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+            "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n")
+    cases = {
+        "negative_list_length": head + "-3 0 1 2\n",
+        "huge_list_length": head + "99999999999 0 1 2\n",
+        "negative_index": head + "3 0 1 -2\n",
+        "index_past_uint32": head + "3 0 1 99999999999\n",
+        "not_a_number": head + "3 a b c\n",
+        "short_polygon_then_end": head + "2 0 1\n",
+        "second_vertex_element": head.replace("element face 1", "element vertex 1\nproperty float x\nproperty float y\n"
+                                              "property float z\nelement face 1") + "5 5 5\n3 0 0 0\n",
+        "vertex_count_past_uint32": head.replace("element vertex 3", "element vertex 99999999999"),
+        "binary_truncated": None,
+    }
+    for name, text in cases.items():
+        f = tmp_path / (name + ".ply")
+        if text is None:
+            src = open(os.path.join(os.path.dirname(__file__), "golden", "models", "CBbunny.ply"), "rb").read()
+            f.write_bytes(src[: len(src) // 2])
+        else:
+            f.write_text(text)
+        if name == "short_polygon_then_end":          # a two-corner polygon makes no triangle: a valid, empty model
+            pos, aux, idx = pt.load_ply(str(f))
+            assert idx.shape[0] == 0 and pos.shape[0] == 3
+            continue
+        with pytest.raises(pt.PtError):
+            pt.load_ply(str(f))
+    # elements without properties carry no data, whatever their count says: must not loop 2^64 times
+    f = tmp_path / "empty_elements.ply"
+    f.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                 "element foo 18446744073709551615\nelement face 18446744073709551615\nend_header\n0 0 0\n1 0 0\n0 1 0\n")
+    pos, aux, idx = pt.load_ply(str(f))
+    assert pos.shape[0] == 3 and idx.shape[0] == 0
+    # colours out of range saturate instead of wrapping
+    f = tmp_path / "colours.ply"
+    f.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\n"
+                 "property int red\nproperty int green\nproperty int blue\nend_header\n0 0 0 300 -5 17\n")
+    pos, aux, idx = pt.load_ply(str(f))
+    assert aux["color"][0].tolist() == [255, 0, 17, 255]
+
+
 def _check_bvh_invariants(nodes, ridx, pos):
     T = ridx.shape[0]
     N = nodes.shape[0]
