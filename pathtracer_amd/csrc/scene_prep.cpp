@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #pragma STDC FP_CONTRACT OFF
@@ -33,6 +34,37 @@ inline void digest_box(const PtBVHNode& n, float c[3], uint16_t h[6])
 
 void set_err(char* err, size_t n, const char* msg) { if (err && n) snprintf(err, n, "%s", msg); }
 
+/* Is the array the pre-order tree BuildBVH lays down (BVH.cpp:124, 284-304)?  Node i's subtree occupies [i, end): a leaf
+ * has end = i + 1, an interior node its left child at i + 1 and its right child inside (i + 1, end); every node's skip
+ * link names `end`, or 0 where that is the end of the array; every triangle sits in exactly one leaf.  Anything else -
+ * a child index pointing back up, a skip link into the middle of a subtree - would send a walk round in circles on
+ * the device, so it is refused here. */
+const char* validate_tree(const PtBVHNode* nodes, uint32_t num_nodes, uint32_t num_triangles)
+{
+    if (num_triangles == 0 || num_nodes != 2 * num_triangles - 1) return "node count is not 2T-1";
+    std::vector<uint8_t> seen(num_triangles, 0);
+    std::vector<uint32_t> st = { 0u, num_nodes };
+    while (!st.empty()) {
+        const uint32_t end = st.back(); st.pop_back();
+        const uint32_t i = st.back(); st.pop_back();
+        const PtBVHNode& n = nodes[i];
+        if ((uint32_t)n.next != (end == num_nodes ? 0u : end)) return "a skip link does not name the end of its subtree";
+        if (n.right > 0) {
+            const uint32_t r = (uint32_t)n.right;
+            if (r <= i + 1 || r >= end) return "a right child lies outside its parent's subtree";
+            st.push_back(r); st.push_back(end);
+            st.push_back(i + 1); st.push_back(r);
+        } else {
+            if (end != i + 1) return "a leaf is followed by nodes of its own subtree";
+            const uint32_t off = (uint32_t)(-(int64_t)n.right);
+            if (off % 3 != 0 || off / 3 >= num_triangles) return "leaf offset out of range";
+            if (seen[off / 3]) return "two leaves hold the same triangle";
+            seen[off / 3] = 1;
+        }
+    }
+    return nullptr;
+}
+
 }  // namespace
 
 extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
@@ -41,6 +73,7 @@ extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
 try {
     if (!nodes || !positions || !indices || !tris || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh: null argument"); return -1; }
     if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
+    if (const char* why = validate_tree(nodes, num_nodes, num_triangles)) { set_err(err, err_len, (std::string("pt_flatten_bvh: ") + why).c_str()); return -3; }
 
     /* interior rank of every reference node (pre-order is kept, so a left child is rank+1 when interior) */
     std::vector<uint32_t> rank(num_nodes);
@@ -139,6 +172,7 @@ extern "C" PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t nu
                                              uint32_t* max_stack, char* err, size_t err_len)
 try {
     if (!nodes || !positions || !indices || !tris || !leaf_ref || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh_compact: null argument"); return -1; }
+    if (const char* why = validate_tree(nodes, num_nodes, num_triangles)) { set_err(err, err_len, (std::string("pt_flatten_bvh_compact: ") + why).c_str()); return -3; }
     std::vector<uint32_t> rank;
     if (int rc = rank_nodes(nodes, num_nodes, num_triangles, rank, err, err_len)) return rc;
     auto child_ref = [&](uint32_t i) { return nodes[i].right > 0 ? rank[i] : (PT_LEAF_BIT | rank[i]); };

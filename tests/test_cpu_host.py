@@ -215,6 +215,31 @@ def test_flatten_pass(bunny):
         pt.flatten_bvh(nodes[:-1], pos, ridx)
 
 
+def test_flatten_pass_refuses_a_malformed_tree(bunny):
+    """A node array that is not the builder's pre-order tree would send a walk round in circles on the device (or the
+    flattening pass itself): a right child that points back up, a skip link into the middle of a subtree, a leaf
+    listed twice.  Each is refused with a reason; the intact array passes."""
+    nodes, pos, idx = bunny["nodes"], bunny["positions"], bunny["indices"]
+    pt.flatten_bvh(nodes, pos, idx)
+    interior = np.nonzero(nodes["right"] > 0)[0]
+    leaves = np.nonzero(nodes["right"] <= 0)[0]
+    deep = interior[len(interior) // 2]
+
+    def broken(edit):
+        bad = nodes.copy()
+        edit(bad)
+        for fn in (pt.flatten_bvh, pt.flatten_bvh_compact):
+            with pytest.raises(pt.PtError):
+                fn(bad, pos, idx)
+
+    broken(lambda b: b["right"].__setitem__(deep, 1))                             # right child = an ancestor's left child
+    broken(lambda b: b["right"].__setitem__(deep, int(deep) + 1))                 # right child = own left child
+    broken(lambda b: b["next"].__setitem__(deep + 1, int(b["next"][deep + 1]) + 1))   # skip link past the subtree's end
+    broken(lambda b: b["next"].__setitem__(0, 5))                                 # the root's skip link must end the walk
+    broken(lambda b: b["right"].__setitem__(leaves[3], int(b["right"][leaves[7]])))   # one triangle in two leaves
+    broken(lambda b: b["right"].__setitem__(leaves[3], -1))                       # leaf offset not a multiple of 3
+
+
 def test_fill_constants():
     c = pt.fill_constants(1920, 1080, 5, 100, 199, frame_index=7)
     assert c["numRays"][0] == 5 and c["frameIndex"][0] == 7 and c["numBVHNodes"][0] == 199
