@@ -752,6 +752,10 @@ PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const
     FramePipe& p = ctx->pipe[0];                        /* the dispatch-site calls that follow work on pipe 0 */
     if (slots) { HIPCHK(hipMemcpyAsync(p.dStack, slots, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyHostToDevice, ctx->stream)); ctx->rngPipe = 0; }
     if (jobs) {
+        /* a job is a slot index the kernels follow: one past the ray stack would be read and written on the device */
+        const uint64_t limit = (uint64_t)px * ctx->slots;
+        for (size_t i = 0; i < px; i++)
+            if (jobs[i].index != PT_JOB_DEAD && jobs[i].index >= limit) return ctx->fail(-1, "pt_upload_raystack: a job names a slot outside the ray stack");
         uint32_t n = (uint32_t)px;
         HIPCHK(hipMemcpyAsync(p.dJobs[p.curJobs], jobs, px * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(p.dCtr + CTR_NJOBS, &n, 4, hipMemcpyHostToDevice, ctx->stream));

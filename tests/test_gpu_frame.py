@@ -429,3 +429,37 @@ def test_two_contexts_and_scene_swap(oracle_lib, monkey, bunny):
         _compare(b, fr_b)                                  # untouched by all that
     finally:
         a.close(); b.close()
+
+
+def test_uploaded_ray_stack_and_jobs_are_what_gets_traced(gpu_ctx, oracle_lib, monkey):
+    """pt_upload_raystack: the host edits the ray stack and the job list between dispatch sites (a third of the jobs
+    killed, some rays turned round), and the passes that follow work on exactly that; a job that names a slot outside
+    the ray stack is refused."""
+    W, H, NR = 96, 64, 3
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    c = _consts(monkey, W, H, NR, 1, {})
+    gpu_ctx.set_constants(c)
+    gpu_ctx.launch()
+    oracle.launch(osc, fr, c)
+    slots, jobs = gpu_ctx.readback_raystack()
+    jobs = jobs.copy(); slots = slots.copy()
+    jobs[::3] = 0xFFFFFFFF
+    turned = np.arange(0, W * H, 7) * NR
+    slots["rayDirection"][turned] = -slots["rayDirection"][turned]
+    gpu_ctx.upload_raystack(slots, jobs)
+    fr.stack[:] = slots; fr.jobs[:] = jobs
+    for d in range(NR):
+        gpu_ctx.trace(d)
+        oracle.trace(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+    got, gjobs = gpu_ctx.readback_raystack()
+    assert np.array_equal(got.view(np.uint8), fr.stack.view(np.uint8))
+    assert np.array_equal(np.sort(gjobs[gjobs != 0xFFFFFFFF]), np.sort(fr.jobs[fr.jobs != 0xFFFFFFFF]))
+    gpu_ctx.resolve_accumulate()
+    oracle.composite(fr, c)
+    _compare(gpu_ctx, fr)
+    bad = jobs.copy(); bad[5] = W * H * NR
+    with pytest.raises(pt.PtError):
+        gpu_ctx.upload_raystack(None, bad)
+    gpu_ctx.upload_raystack(None, jobs)          # the limit itself minus one is fine
+    ok = jobs.copy(); ok[5] = W * H * NR - 1
+    gpu_ctx.upload_raystack(None, ok)
