@@ -245,7 +245,8 @@ PT_API int pt_scene_upload(PtContext* ctx,
                            const uint16_t* blue_noise /* 65536 entries */);
 
 /* Replaces the per-resolution resources of PathTracer.cpp:378-459 (bindings 5,6,9,10):
- * current image RGBA16F, accumulation RGBA32F, ray stack 48 B x W x H x max_slots, jobs. */
+ * current image RGBA16F, accumulation RGBA32F, ray stack 48 B x W x H x max_slots, jobs.
+ * Constants set earlier for another size (or more slots) are dropped: call pt_set_constants again. */
 PT_API int pt_resize(PtContext* ctx, uint32_t width, uint32_t height, uint32_t max_slots);
 
 /* Replaces the transient uniform slice written at PathTracer.cpp:731-752 (binding 0). */

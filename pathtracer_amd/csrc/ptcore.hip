@@ -490,6 +490,9 @@ PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
     if (int rc = sync_all(ctx)) return rc;
     free_frame(ctx);
     size_t px = (size_t)W * H;
+    /* constants set for another size would make the launch pass index pixels this size does not have */
+    if (ctx->haveConsts && ((uint32_t)ctx->consts.viewportSize[0] != W || (uint32_t)ctx->consts.viewportSize[1] != H || ctx->consts.numRays > max_slots))
+        ctx->haveConsts = false;
     ctx->W = W; ctx->H = H; ctx->slots = max_slots;
     HIPCHK(hipMalloc((void**)&ctx->dAccum, px * 16));
     HIPCHK(hipMalloc((void**)&ctx->dCurrent, px * 8));

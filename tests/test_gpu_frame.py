@@ -234,6 +234,12 @@ def test_error_behaviour(oracle_lib, bunny):
         ctx.set_constants(pt.fill_constants(64, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))
         ctx.render_sample(1)
         assert (ctx.readback_accumulation()[..., 3] == 1).all()
+        ctx.resize(32, 48, 2)                               # the 64 x 64 constants do not fit this size: dropped
+        with pytest.raises(pt.PtError):
+            ctx.launch()
+        ctx.set_constants(pt.fill_constants(32, 48, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))
+        ctx.render_sample(2)
+        assert (ctx.readback_accumulation()[..., 3] == 1).all()
     finally:
         ctx.close()
 
