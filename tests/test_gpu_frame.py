@@ -469,3 +469,36 @@ def test_uploaded_ray_stack_and_jobs_are_what_gets_traced(gpu_ctx, oracle_lib, m
     gpu_ctx.upload_raystack(None, jobs)          # the limit itself minus one is fine
     ok = jobs.copy(); ok[5] = W * H * NR - 1
     gpu_ctx.upload_raystack(None, ok)
+
+
+def test_contexts_give_their_device_memory_back(bunny):
+    """Create, use (scene, frame pipes, ordering scratch, spill areas) and destroy a context several times: the free
+    device memory afterwards is what it was before, to within what the runtime keeps for itself."""
+    import torch
+    torch.cuda.synchronize()
+
+    def cycle():
+        ctx = pt.PathTracer(0)
+        try:
+            helpers.upload(ctx, bunny, pt.default_lights(), pt.load_blue_noise())
+            ctx.resize(640, 480, 4)
+            ctx.set_constants(pt.fill_constants(640, 480, 4, bunny["indices"].shape[0], bunny["nodes"].shape[0], **BUNNY_CAM))
+            ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 4)
+            ctx.render_samples(1, 8)
+            ctx.resize(320, 240, 2)                          # frees and rebuilds the per-resolution buffers
+            ctx.set_constants(pt.fill_constants(320, 240, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0], **BUNNY_CAM))
+            ctx.render_samples(9, 4)
+            ctx.set_option(core.OPT_SORT_RAYS, 1)
+            rays = helpers.random_rays(bunny["nodes"][0]["a"], bunny["nodes"][0]["b"], 50_000, seed=3)
+            ctx.trace_rays(rays)
+            helpers.upload(ctx, bunny, pt.default_lights(), pt.load_blue_noise())      # a second scene replaces the first
+            ctx.synchronize()
+        finally:
+            ctx.close()
+
+    cycle()                                                  # first use: the runtime's own one-time allocations
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(4):
+        cycle()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned"
