@@ -273,6 +273,7 @@ class PathTracer:
         if rc != 0:
             raise PtError(f"pt_ctx_create failed ({rc}): {self._L.pt_last_error(None).decode()}")
         self._h = h
+        self.device_id = device_id
         self.W = self.H = self.slots = 0
         self.num_triangles = self.num_nodes = 0
 

@@ -37,7 +37,7 @@ def allreduce_accumulation_torch(ctx, group=None):
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 3, "strides": None}
 
     ctx.synchronize()
-    t = torch.as_tensor(_Alias(ctx.accumulation_device_ptr(), ctx.W * ctx.H * 4), device=torch.device("cuda", torch.cuda.current_device()))
+    t = torch.as_tensor(_Alias(ctx.accumulation_device_ptr(), ctx.W * ctx.H * 4), device=torch.device("cuda", ctx.device_id))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     torch.cuda.synchronize()
     return t
