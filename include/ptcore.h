@@ -224,7 +224,7 @@ enum {
     PT_OPT_SORT_RAYS      = 9,   /* pt_trace_rays orders a batch by the cell of the scene box each origin lies in before
                                     tracing it (results are stored under the rays' own indices and do not change):
                                     0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
-    PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 3): the ordering grid has 2^bits cells per axis */
+    PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 4): the ordering grid has 2^bits cells per axis */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..4 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and pair of streams; results do not depend on it */
 };
