@@ -38,7 +38,7 @@ OPT_FRAMES_IN_FLIGHT = 7
 OPT_SORT_RAYS = 9               # 0 = never, 1 = always, 2 = batches of 2^20 rays or more (default)
 OPT_SORT_BITS = 10
 OPT_RECORD_LAYOUT = 8           # 0 = 64 B records (default), 1 = 48 B records when every box can be encoded
-TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED = 0, 1, 2
+TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED, TRAVERSAL_CERTIFIED = 0, 1, 2, 3
 
 
 class PtError(RuntimeError):

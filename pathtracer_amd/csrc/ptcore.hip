@@ -101,6 +101,8 @@ struct PtContext {
     bool accumEmpty = true;     /* no sample in the accumulation since pt_resize / pt_clear_accumulation */
     float4* dAccum = nullptr; uint2* dCurrent = nullptr;
     uint32_t* dFetch = nullptr; unsigned long long* dStats = nullptr;      /* pt_trace_rays: id counter, visit statistics */
+    uint32_t* dFlagList = nullptr; uint32_t* dFlagCtr = nullptr; uint64_t flagCapacity = 0;     /* certified walk: rays to trace again, {count, fetch counter} */
+    bool boxesNest = false;     /* every child box inside its parent's, every triangle inside its leaf's: what the certified walk rests on */
     uint32_t* dSortOrder = nullptr; uint16_t* dSortKeys = nullptr; uint32_t* dSortBins = nullptr;   /* ray ordering: scratch for sortCapacity rays, [0..4096) counts, [4096..8192) cursors */
     uint64_t sortCapacity = 0;
 
@@ -194,7 +196,10 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
     dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
     a.refillMin = (uint32_t)refill_min(ctx, shape);
-    const int trav = ctx->optTraversal;
+    /* 3 (certified walk) exists for closest-hit batches of pt_trace_rays, which launches it itself; any-hit batches get
+       the near-first walk (their verdict does not depend on the order), every other pass the reference-order walk */
+    int trav = ctx->optTraversal;
+    if (trav == 3) trav = (MODE == MODE_RAYS && ANYHIT) ? 2 : 1;
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
@@ -343,6 +348,7 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
     for (FramePipe& p : ctx->pipe) destroy_pipe(ctx, p);
     dfree(ctx->dFetch); dfree(ctx->dStats);
     dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); dfree(ctx->dSortBins);
+    dfree(ctx->dFlagList); dfree(ctx->dFlagCtr);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
@@ -365,7 +371,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
 {
     if (!ctx) return -1;
     switch (option) {
-        case PT_OPT_TRAVERSAL: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_TRAVERSAL must be 0, 1 or 2"); ctx->optTraversal = value; return 0;
+        case PT_OPT_TRAVERSAL: if (value < 0 || value > 3) return ctx->fail(-1, "PT_OPT_TRAVERSAL must be 0, 1, 2 or 3"); ctx->optTraversal = value; return 0;
         case PT_OPT_STALE_SLOTS: ctx->optStale = value != 0; return 0;
         case PT_OPT_RESEED: ctx->optReseed = value != 0; return 0;
         case PT_OPT_PERSIST_BLOCKS: if (value < 1 || value > 8) return ctx->fail(-1, "PT_OPT_PERSIST_BLOCKS must be 1..8"); ctx->optBlocksPerCU = value; ctx->userBlocks = true; return 0;
@@ -431,6 +437,18 @@ try {
             return ctx->fail(-1, ebuf);
     }
     ctx->maxStack = maxStack;
+    /* the certified walk skips a subtree when the ray enters its box beyond max_t, which is sound only if everything in the
+       subtree lies inside that box: true of every tree pt_build_bvh makes, checked here because the array is the caller's */
+    ctx->boxesNest = true;
+    for (uint32_t i = 0; i < N && ctx->boxesNest; i++) {
+        const PtBVHNode& n = nodes[i];
+        auto inside = [&](const float* lo, const float* hi) { for (int k = 0; k < 3; k++) if (!(lo[k] >= n.a[k] && hi[k] <= n.b[k])) return false; return true; };
+        if (n.right > 0) ctx->boxesNest = inside(nodes[i + 1].a, nodes[i + 1].b) && inside(nodes[n.right].a, nodes[n.right].b);
+        else {
+            const uint32_t t = (uint32_t)(-n.right) / 3u;
+            for (int v = 0; v < 3 && ctx->boxesNest; v++) { const float* p = positions + 4 * (size_t)indices[3 * (size_t)t + v]; ctx->boxesNest = inside(p, p); }
+        }
+    }
     ctx->lastLeaf = (uint32_t)(-nodes[N - 1].right) / 3u;          /* the last node of a pre-order array is a leaf */
     for (int k = 0; k < 3; k++) {      /* root box digest, as for every other box (intersections.glsl:3-5) */
         ctx->rootC[k] = (ctx->rootBox[k] + ctx->rootBox[3 + k]) * 0.5f;
@@ -841,8 +859,36 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
         HIPCHK(hipGetLastError());
         a.order = ctx->dSortOrder;
     }
+    const bool certified = ctx->optTraversal == 3 && !any_hit && !ctx->compact && ctx->boxesNest;
+    if (certified) {
+        if (ctx->flagCapacity < num_rays) {
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->dFlagList); ctx->flagCapacity = 0;
+            HIPCHK(hipMalloc((void**)&ctx->dFlagList, num_rays * 4));
+            ctx->flagCapacity = num_rays;
+        }
+        if (!ctx->dFlagCtr) HIPCHK(hipMalloc((void**)&ctx->dFlagCtr, 2 * 4));
+        HIPCHK(hipMemsetAsync(ctx->dFlagCtr, 0, 2 * 4, ctx->stream));
+    }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    int rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);
+    int rc = 0;
+    if (certified) {
+        /* first every ray by the certified walk, which lists the few it cannot vouch for; then those by the reference-order walk */
+        if ((rc = ensure_overflow(ctx))) return rc;
+        a.overflow = ctx->dOverflow; a.overflowEntries = ctx->overflowEntries;
+        a.flagList = ctx->dFlagList; a.flagCount = ctx->dFlagCtr;
+        const int shape = a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH;
+        a.refillMin = (uint32_t)refill_min(ctx, shape);
+        dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
+        if (stats) hipLaunchKernelGGL((k_trace_cert<true>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_trace_cert<false>), grid, block, 0, ctx->stream, a);
+        HIPCHK(hipGetLastError());
+        TraceArgs b = a;
+        b.order = ctx->dFlagList; b.countPtr = ctx->dFlagCtr; b.fetchCounter = ctx->dFlagCtr + 1; b.flagList = nullptr; b.flagCount = nullptr;
+        rc = launch_trace<MODE_RAYS, false>(ctx, b, stats != nullptr, ctx->stream, 0);       /* traversal 3 maps to the reference-order walk there */
+    } else {
+        rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);
+    }
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->evPending = true;

@@ -89,6 +89,9 @@ struct TraceArgs {
     const PtShadowRay* shadowRays;
     /* counting build */
     unsigned long long* stats;       /* {box tests, triangle tests, records fetched, rays} */
+    /* certified walk */
+    uint32_t*        flagList;       /* indices of the rays whose result the walk could not certify */
+    uint32_t*        flagCount;
 };
 
 /* ---- per-mode ray fetch / result store ------------------------------------------------------- */
@@ -565,3 +568,210 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     }
 }
 
+/* ---- certified walk: the reference's answer without the reference's visit order ----------------
+ *
+ * The reference's closest hit depends on its visit order only because its fp16 box test is not conservative: a
+ * subtree can be skipped (max_t <= tmin of its box) although it holds a closer triangle, and whether that happens
+ * depends on what max_t was when the walk came by.  k_trace_cert walks near child first like k_trace_flat<ORDERED>,
+ * with two changes that make its answer provably the reference's for almost every ray, and tell which rays are left:
+ *
+ *  1. it skips a subtree only when that is safe in every order: the box's fp16 verdict minus its max_t part (which
+ *     does not depend on order: a subtree the reference can never enter is not entered here either) must pass, and
+ *     the subtree is skipped on distance only if a lower bound of the distance at which the ray enters the box the
+ *     builder made (entry_bound: the digested box widened by every rounding between the builder's fp32 box and here,
+ *     slab test in fp32 with slack) lies beyond max_t.  Every triangle of a subtree lies inside its box, so nothing
+ *     skipped this way can be nearer than what the walk already holds.  The walk therefore ends with the nearest
+ *     triangle X among all the reference could ever reach, whatever the order.
+ *  2. it keeps, for the hit X it holds, the largest fp16 tmin G among the boxes on the way down to X, and the smallest
+ *     t among all OTHER triangles it saw the ray hit.  The reference enters a box when its max_t of that moment exceeds
+ *     the box's tmin, and its max_t is the ray's limit or the t of a triangle it has found.  So if no other triangle
+ *     the ray hits has t <= G, and G is below the ray's own limit, the reference enters every box on the way to X
+ *     whenever it comes by, tests X with a max_t that is not below t of X, accepts it, and accepts nothing after it
+ *     but an exact tie: its answer is X, with the same t (same arithmetic in the triangle test).  To be sure of having
+ *     seen every triangle with t <= G the walk skips on distance only beyond max(t of X, G), not beyond t of X.
+ *
+ * A ray is flagged, and traced again by the reference-order walk, when another hit lies at or before G (about one ray
+ * in a thousand: hits on an edge two triangles share, doubled surfaces), when G reaches the ray's limit, when two
+ * triangles tied for the final t, or when its direction has a zero or non-finite component or its origin is not finite
+ * (the bound's arithmetic assumes neither).
+ */
+__device__ __forceinline__ h16 round_down_h16(float v)
+{
+    h16 h = (h16)v;
+    if ((float)h > v) {                       /* rounded up (or overflowed to +inf): one step down */
+        uint16_t b = hbits(h);
+        b = (b & 0x8000u) ? (uint16_t)(b + 1u) : (b == 0u ? (uint16_t)0x8001u : (uint16_t)(b - 1u));
+        h = hfrombits(b);
+    }
+    return h;
+}
+
+/* Lower bounds of the ray's entry distance into the two boxes of one interior record.  dx,dy,dz = c - o as box_pair
+ * computes them; inv = 1/d in fp32 (finite and non-zero: the caller does not walk other rays). */
+__device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float invx, float invy, float invz,
+                                            h16x2 ax, h16x2 ay, h16x2 az, h16x2 bx, h16x2 by, h16x2 bz, float& boundL, float& boundR)
+{
+    auto axis = [](f32x2 d, float inv, h16x2 ha, h16x2 hb) {
+        const f32x2 fa = __builtin_convertvector(ha, f32x2), fb = __builtin_convertvector(hb, f32x2);       /* exact */
+        /* |true a - (c + ha)| <= |ha| 2^-11 (2^-25 for a subnormal half) from the digest's rounding; the sums below
+           add at most (|d| + |h|) 2^-22 */
+        f32x2 pad;
+        pad.x = fmaxf(fabsf(fa.x), fabsf(fb.x)) * 0x1p-10f + fabsf(d.x) * 0x1p-20f + 0x1p-24f;
+        pad.y = fmaxf(fabsf(fa.y), fabsf(fb.y)) * 0x1p-10f + fabsf(d.y) * 0x1p-20f + 0x1p-24f;
+        const f32x2 lo = (d + fa) - pad, hi = (d + fb) + pad;
+        const f32x2 t0 = lo * inv, t1 = hi * inv;
+        f32x2 n; n.x = fminf(t0.x, t1.x); n.y = fminf(t0.y, t1.y);
+        return n;
+    };
+    const f32x2 nx = axis(dx, invx, ax, bx), ny = axis(dy, invy, ay, by), nz = axis(dz, invz, az, bz);
+    const float eL = fmaxf(fmaxf(nx.x, ny.x), nz.x), eR = fmaxf(fmaxf(nx.y, ny.y), nz.y);
+    /* the products and the maximum are off by a few parts in 2^24 */
+    boundL = eL - fabsf(eL) * 0x1p-18f; boundR = eR - fabsf(eR) * 0x1p-18f;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
+{
+    __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
+    __shared__ uint16_t sBound[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];      /* entry bound of the waiting child, rounded down */
+    __shared__ uint16_t sGate[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];       /* largest fp16 tmin from the root down to it */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
+    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
+
+    RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
+    bool active = false, pend = false;
+    uint32_t pendIdx = 0;
+    RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
+    h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
+    float invx = 0, invy = 0, invz = 0;
+    uint32_t cur = 0; int sp = 0;
+    bool hit = false, tie = false;
+    int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
+    float pathGate = 0, hitGate = 0;      /* largest fp16 tmin on the way to the current record / to the hit held */
+    float limit0 = 0, otherT = 0;         /* the ray's own max_t; smallest t of any other triangle the ray was seen to hit */
+    unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+    const float NEG_INF = -__builtin_huge_valf();
+
+    const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
+    const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
+
+    auto flag_ray = [&]() { a.flagList[atomicAdd(a.flagCount, 1u)] = (uint32_t)id; };
+
+    auto start_ray = [&](const RayWords& w) {
+        finish_ray<MODE_RAYS>(w, r, exclude, tag);
+        if (COUNT) { nRay++; nBox++; }
+        hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
+        limit0 = r.max_t; otherT = __builtin_huge_valf();
+        rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
+        invx = 1.0f / r.d.x; invy = 1.0f / r.d.y; invz = 1.0f / r.d.z;
+        /* finite and non-zero, all nine: x - x is 0 exactly then, NaN for an infinity or a NaN */
+        const float probe = (invx - invx) + (invy - invy) + (invz - invz) + (r.o.x - r.o.x) + (r.o.y - r.o.y) + (r.o.z - r.o.z) +
+                            (r.d.x - r.d.x) + (r.d.y - r.d.y) + (r.d.z - r.d.z);
+        const bool walkable = probe == 0.0f && invx != 0.0f && invy != 0.0f && invz != 0.0f;
+        float ftmin;
+        bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
+        if (!walkable) { flag_ray(); store_result<MODE_RAYS>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0); }
+        else if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }          /* the root's test is the reference's own: it comes first in every order */
+        else store_result<MODE_RAYS>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
+    };
+
+    for (;;) {
+        const bool canTake = !active && !pend;
+        uint64_t idleMask = __ballot(canTake);
+        int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && pool.exhausted()) break;
+        bool fresh = false;
+        RayWords w;
+        if (pend) { id = pendIdx; pend = false; fresh = issue_ray<MODE_RAYS>(a, id, w); }
+        if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
+            uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
+            if (canTake && nid != ~0ull) {
+                if (a.order) { pendIdx = a.order[nid]; pend = true; }
+                else { id = nid; fresh = issue_ray<MODE_RAYS>(a, id, w); }
+            }
+        }
+
+        if (active) {
+        const bool leaf = (cur & PT_LEAF_BIT) != 0;
+        const uint32_t off = (cur & ~PT_LEAF_BIT) * 64u + (leaf ? a.leafBase : 0u);
+        u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
+        u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
+        u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+        if (COUNT) nRec++;
+        bool needPop = true, done = false;
+
+        if (leaf) {
+            if (COUNT) nTri++;
+            float t, al, be, ga;
+            F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
+            F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
+            F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
+            tri_test(r, p1, e1, e2, t, al, be, ga);
+            /* intersections.glsl:45 in its positive form, against the ray's own limit first */
+            if (t >= r.min_t && t <= limit0 && al >= 0.0f && be >= 0.0f && ga >= 0.0f) {
+                if (t <= r.max_t) {                         /* the reference's acceptance: replaces the hit held */
+                    if (hit) { if (t == r.max_t) tie = true; otherT = fminf(otherT, r.max_t); }
+                    r.max_t = t; hit = true; hitGate = pathGate;
+                    hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w;
+                } else otherT = fminf(otherT, t);
+            }
+        } else {
+            if (COUNT) nBox += 2;
+            bool sL, sR; float tminL, tminR;
+            const f32x2 cx = as_f2(q0.x, q0.y), cy = as_f2(q0.z, q0.w), cz = as_f2(q1.x, q1.y);
+            const h16x2 ax = as_h2(q1.z), ay = as_h2(q1.w), az = as_h2(q2.x), bx = as_h2(q2.y), by = as_h2(q2.z), bz = as_h2(q2.w);
+            box_pair(r, rx, ry, rz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR);
+            const f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
+            float boundL, boundR;
+            entry_bound(dx, dy, dz, invx, invy, invz, ax, ay, az, bx, by, bz, boundL, boundR);
+            /* enter unless the order-independent part of the reference's verdict fails or the box certainly begins beyond
+               everything that still matters */
+            const float reach = fmaxf(r.max_t, hitGate);
+            const bool pL = sL && !(boundL > reach), pR = sR && !(boundR > reach);
+            const uint32_t refL = q3.x, refR = q3.y;
+            const bool rightFirst = pL && pR && tminR < tminL;
+            if (pL && pR) {
+                const uint32_t second = rightFirst ? refL : refR;
+                const float boundSecond = rightFirst ? boundL : boundR, tminSecond = rightFirst ? tminL : tminR;
+                const uint16_t bb = hbits(round_down_h16(boundSecond));
+                const uint16_t gb = hbits((h16)fmaxf(pathGate, tminSecond));             /* exact: both came from fp16 values */
+                if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = second; sBound[wave][sp][lane] = bb; sGate[wave][sp][lane] = gb; }
+                else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, (uint32_t)bb | ((uint32_t)gb << 16));
+                sp++;
+            }
+            if (pL || pR) {
+                const bool goRight = rightFirst || !pL;
+                cur = goRight ? refR : refL;
+                pathGate = fmaxf(pathGate, goRight ? tminR : tminL);
+                needPop = false;
+            }
+        }
+
+        while (needPop) {
+            if (sp == 0) { done = true; break; }
+            sp--;
+            const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
+            uint32_t ref = sRef[wave][e][lane]; uint16_t bb = sBound[wave][e][lane], gb = sGate[wave][e][lane];
+            asm volatile("" : "+v"(ref));
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; bb = (uint16_t)o.y; gb = (uint16_t)(o.y >> 16); }
+            if (!((float)hfrombits(bb) > fmaxf(r.max_t, hitGate))) { cur = ref; pathGate = (float)hfrombits(gb); needPop = false; }
+        }
+
+        if (done) {
+            if (hit && (tie || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
+            store_result<MODE_RAYS>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, 0, 0, 0, 0);
+            active = false;
+        }
+        }   /* if (active) */
+
+        if (fresh) start_ray(w);
+    }
+    if (COUNT) {
+        atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
+    }
+}

@@ -52,7 +52,8 @@ for mode in [int(m) for m in args.modes.split(",")]:
     if ref_hits is None:
         ref_hits = hits
     diff = ((hits["i1"] != ref_hits["i1"]) | (hits["i2"] != ref_hits["i2"]) | (hits["i3"] != ref_hits["i3"])).mean()
-    print(f"mode {mode}: box/ray {st[0]/n:.1f} tri/ray {st[1]/n:.2f} rec/ray {st[2]/n:.1f} hit rate {(hits['i1']>=0).mean():.3f} diff vs first mode {diff:.2e}", flush=True)
+    tdiff = int((hits["t"].view(np.uint32) != ref_hits["t"].view(np.uint32)).sum())
+    print(f"mode {mode}: box/ray {st[0]/n:.1f} tri/ray {st[1]/n:.2f} rec/ray {st[2]/n:.1f} hit rate {(hits['i1']>=0).mean():.3f} diff vs first mode {diff:.2e} (t differs bitwise on {tdiff} rays; rays walked / rays {st[3]/n:.5f})", flush=True)
     for blocks in [int(b) for b in args.blocks.split(",")]:
         for refill in [int(r) for r in args.refill.split(",")]:
           for chunk in [int(c) for c in args.chunk.split(",")]:

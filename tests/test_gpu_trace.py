@@ -20,7 +20,7 @@ def _check(ctx, model, osc, rays, any_hit, traversal, exact=True):
     hits = ctx.trace_rays(rays, any_hit=any_hit)
     ref = osc.trace(rays, any_hit=any_hit)
     hit_g, hit_o = hits["i1"] >= 0, ref["i1"] >= 0
-    if any_hit and traversal == core.TRAVERSAL_FLAT_ORDERED:
+    if any_hit and traversal in (core.TRAVERSAL_FLAT_ORDERED, core.TRAVERSAL_CERTIFIED):
         # any-hit only promises "some hit iff the reference finds one"
         assert np.array_equal(hit_g, hit_o)
         return 0.0
@@ -37,7 +37,7 @@ def _check(ctx, model, osc, rays, any_hit, traversal, exact=True):
     return float((~same).mean())
 
 
-@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT])
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED])
 @pytest.mark.parametrize("any_hit", [False, True])
 def test_bunny_random_rays_exact(gpu_ctx, oracle_lib, bunny, traversal, any_hit):
     helpers.upload(gpu_ctx, bunny)
@@ -46,7 +46,7 @@ def test_bunny_random_rays_exact(gpu_ctx, oracle_lib, bunny, traversal, any_hit)
     _check(gpu_ctx, bunny, osc, rays, any_hit, traversal)
 
 
-@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT])
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED])
 def test_bunny_camera_rays_exact(gpu_ctx, oracle_lib, bunny, traversal):
     helpers.upload(gpu_ctx, bunny)
     osc = helpers.oracle_scene(bunny)
@@ -55,7 +55,7 @@ def test_bunny_camera_rays_exact(gpu_ctx, oracle_lib, bunny, traversal):
 
 
 @pytest.mark.parametrize("model_name", ["monkey", "courtyard_small"])
-@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT])
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED])
 def test_other_scenes_exact(gpu_ctx, oracle_lib, request, model_name, traversal):
     model = request.getfixturevalue(model_name)
     helpers.upload(gpu_ctx, model)
@@ -121,7 +121,10 @@ def test_edge_cases(gpu_ctx, oracle_lib, bunny):
     rays["o"][:100] += 50.0
     rays["d"][100:200] = (1.0, 0.0, 0.0)
     rays["d"][200:300] = (0.0, -1.0, 0.0)
-    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT):
+    rays["o"][300:310] = np.nan                      # not traceable: a miss everywhere, and nothing may hang on it
+    rays["d"][310:320] = np.inf
+    rays["max_t"][320:400] = np.linspace(0.05, 2.0, 80, dtype=np.float32)      # limits that end inside the model
+    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED):
         _check(gpu_ctx, bunny, osc, rays[:1], False, trav)
         _check(gpu_ctx, bunny, osc, rays, False, trav)
         _check(gpu_ctx, bunny, osc, rays, True, trav)
@@ -136,7 +139,7 @@ def test_single_triangle_scene(gpu_ctx, oracle_lib):
     helpers.upload(gpu_ctx, model)
     osc = helpers.oracle_scene(model)
     rays = helpers.random_rays((-1, -1, -1), (1, 1, 1), 5000, seed=4)
-    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED):
+    for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED, core.TRAVERSAL_CERTIFIED):
         _check(gpu_ctx, model, osc, rays, False, trav)
 
 
@@ -274,9 +277,10 @@ def test_random_triangle_soups_exact(gpu_ctx, oracle_lib, kind):
         osc = helpers.oracle_scene(model)
         lo, hi = nodes[0]["a"], nodes[0]["b"]
         rays = np.concatenate([helpers.random_rays(lo, hi, 3000, seed=n), helpers.random_rays(lo, hi, 1000, seed=n + 1, inside=False)])
-        for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT):
+        for trav in (core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED):
             _check(gpu_ctx, model, osc, rays, False, trav)
             _check(gpu_ctx, model, osc, rays, True, trav)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
         hits = gpu_ctx.trace_rays(rays)         # default order: same verdicts; ids may differ only on near-ties
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
         near = gpu_ctx.trace_rays(rays)
@@ -312,7 +316,7 @@ def test_deep_stacks_spill_past_the_lds_part(gpu_ctx, oracle_lib):
     rays["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     rays["min_t"], rays["max_t"] = 0.001, 1e5
     try:
-        for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_REFERENCE_LAYOUT):
+        for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_CERTIFIED):
             _check(gpu_ctx, model, osc, rays, False, trav)
             _check(gpu_ctx, model, osc, rays, True, trav)
         _check(gpu_ctx, model, osc, rays, False, core.TRAVERSAL_FLAT_ORDERED, exact=False)
@@ -321,3 +325,54 @@ def test_deep_stacks_spill_past_the_lds_part(gpu_ctx, oracle_lib):
         assert st[0] / (m // 2) > 2 * n * 0.9          # the corner rays really test nearly every box
     finally:
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+
+
+def test_certified_walk_equals_reference_order_at_scale(gpu_ctx):
+    """PT_OPT_TRAVERSAL = 3 against = 1 (which the other tests tie to the oracle bit for bit) on the device, at a size the
+    oracle could not serve: 2^23 incoherent rays on a 400 k-triangle stand-in, ordered and as given, plus rays aimed
+    along the edges triangles share and rays whose limit ends on the surface they hit - the cases the certificate
+    exists for.  Ids and t must be identical on every ray; the share of rays that needed the second pass is printed."""
+    pos, aux, idx = pt.scenes.courtyard(400_000, seed=3)
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 8)
+    gpu_ctx.upload_scene(pos, aux, ridx, nodes)
+    n = 1 << 23
+    d_rays, d_hits = gpu_ctx.alloc(n * 32), gpu_ctx.alloc(n * 16)
+    try:
+        gpu_ctx.generate_rays(d_rays, n, seed=77)
+        rays = d_rays.to_host(pt.RAY_DT)
+        # a quarter of the rays re-aimed at points on triangle edges and vertices, from their own origins
+        rng = np.random.default_rng(5)
+        k = n // 4
+        tri = rng.integers(0, ridx.shape[0], k)
+        p0, p1 = pos[ridx[tri, 0], :3], pos[ridx[tri, 1], :3]
+        w = rng.random((k, 1), dtype=np.float32)
+        w[: k // 4] = 0.0                                    # exactly a vertex
+        target = p0 * (1 - w) + p1 * w
+        d = target - rays["o"][:k]
+        rays["d"][:k] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)
+        # and an eighth with a limit that ends within a hair of the first surface (found with the exact walk below)
+        d_rays.from_host(rays)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        gpu_ctx.trace_rays_device(d_rays, n, d_hits)
+        first = d_hits.to_host(pt.HIT_DT)
+        sel = np.arange(k, k + n // 8)
+        scale = rng.choice(np.array([1.0, 1.0 + 1e-7, 1.0 - 1e-7, 1.0 + 1e-3, 1.0 - 1e-3, 1.0 + 2e-4], dtype=np.float32), sel.shape[0])
+        hit = first["i1"][sel] >= 0
+        rays["max_t"][sel[hit]] = first["t"][sel[hit]] * scale[hit]
+        d_rays.from_host(rays)
+        for sort in (0, 1):
+            gpu_ctx.set_option(core.OPT_SORT_RAYS, sort)
+            gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+            gpu_ctx.trace_rays_device(d_rays, n, d_hits)
+            ref = d_hits.to_host(pt.HIT_DT)
+            gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+            st = gpu_ctx.trace_rays_device(d_rays, n, d_hits, want_stats=True)
+            got = d_hits.to_host(pt.HIT_DT)
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), \
+                f"{int((got.view(np.uint32).reshape(-1, 4) != ref.view(np.uint32).reshape(-1, 4)).any(axis=1).sum())} rays differ"
+            print(f"sort {sort}: {int(st[3]) - n} of {n} rays went to the second pass; hit rate {(ref['i1'] >= 0).mean():.3f}")
+            assert int(st[3]) - n < n // 50
+    finally:
+        gpu_ctx.set_option(core.OPT_SORT_RAYS, 2)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        d_rays.free(); d_hits.free()
