@@ -607,26 +607,29 @@ __device__ __forceinline__ h16 round_down_h16(float v)
 }
 
 /* Lower bounds of the ray's entry distance into the two boxes of one interior record.  dx,dy,dz = c - o as box_pair
- * computes them; inv = 1/d in fp32 (finite and non-zero: the caller does not walk other rays). */
+ * computes them; inv = 1/d in fp32 (finite and non-zero: the caller does not walk other rays).
+ * Per axis the box is widened to [c - e, c + e] with e = max(|ha|, |hb|) (1 + 2^-10) + |c - o| 2^-20 + 2^-24, which
+ * contains the builder's fp32 box (|true a - (c + ha)| <= |ha| 2^-11, or 2^-25 for a subnormal half, from the digest's
+ * rounding) with room for every rounding below; the near plane of that slab lies at (c - o) inv - e |inv|.  The fused
+ * multiply-adds here are this bound's own arithmetic, not the reference's. */
 __device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float invx, float invy, float invz,
                                             h16x2 ax, h16x2 ay, h16x2 az, h16x2 bx, h16x2 by, h16x2 bz, float& boundL, float& boundR)
 {
     auto axis = [](f32x2 d, float inv, h16x2 ha, h16x2 hb) {
-        const f32x2 fa = __builtin_convertvector(ha, f32x2), fb = __builtin_convertvector(hb, f32x2);       /* exact */
-        /* |true a - (c + ha)| <= |ha| 2^-11 (2^-25 for a subnormal half) from the digest's rounding; the sums below
-           add at most (|d| + |h|) 2^-22 */
-        f32x2 pad;
-        pad.x = fmaxf(fabsf(fa.x), fabsf(fb.x)) * 0x1p-10f + fabsf(d.x) * 0x1p-20f + 0x1p-24f;
-        pad.y = fmaxf(fabsf(fa.y), fabsf(fb.y)) * 0x1p-10f + fabsf(d.y) * 0x1p-20f + 0x1p-24f;
-        const f32x2 lo = (d + fa) - pad, hi = (d + fb) + pad;
-        const f32x2 t0 = lo * inv, t1 = hi * inv;
-        f32x2 n; n.x = fminf(t0.x, t1.x); n.y = fminf(t0.y, t1.y);
+        const h16x2 eh = __builtin_elementwise_max(as_h2(__builtin_bit_cast(uint32_t, ha) & 0x7FFF7FFFu),
+                                                   as_h2(__builtin_bit_cast(uint32_t, hb) & 0x7FFF7FFFu));
+        const f32x2 e = __builtin_convertvector(eh, f32x2);                                                   /* exact */
+        f32x2 n;
+        const float e0 = __builtin_fmaf(fabsf(d.x), 0x1p-20f, __builtin_fmaf(e.x, 1.0f + 0x1p-10f, 0x1p-24f));
+        const float e1 = __builtin_fmaf(fabsf(d.y), 0x1p-20f, __builtin_fmaf(e.y, 1.0f + 0x1p-10f, 0x1p-24f));
+        n.x = __builtin_fmaf(d.x, inv, -fabsf(e0 * inv));
+        n.y = __builtin_fmaf(d.y, inv, -fabsf(e1 * inv));
         return n;
     };
     const f32x2 nx = axis(dx, invx, ax, bx), ny = axis(dy, invy, ay, by), nz = axis(dz, invz, az, bz);
     const float eL = fmaxf(fmaxf(nx.x, ny.x), nz.x), eR = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-    /* the products and the maximum are off by a few parts in 2^24 */
-    boundL = eL - fabsf(eL) * 0x1p-18f; boundR = eR - fabsf(eR) * 0x1p-18f;
+    /* the products and the reciprocal are off by a few parts in 2^24 */
+    boundL = __builtin_fmaf(-fabsf(eL), 0x1p-18f, eL); boundR = __builtin_fmaf(-fabsf(eR), 0x1p-18f, eR);
 }
 
 template <bool COUNT>
