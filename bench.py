@@ -174,7 +174,8 @@ def main():
             "triangles": int(ridx.shape[0]),
             "bvh_nodes": int(nodes.shape[0]),
             "traversal": {0: "reference 32 B nodes, stackless", 1: "flattened 64 B records, reference visit order",
-                          2: "flattened 64 B records, near child first"}[trav],
+                          2: "flattened 64 B records, near child first",
+                          3: "flattened 64 B records, certified walk (hits identical to the reference order's)"}[trav],
             "ray_ordering": "each batch is traced in the order of its origin cells (16^3 grid over the scene box); the order is "
                             "built inside the timed step, results are stored under the rays' own indices",
             "other_kernels_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 3),
@@ -205,10 +206,16 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pos, aux, ridx, nodes, d_rays, args.cpu_seconds)
+    certified = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            certified = certified_walk(ctx, d_rays, d_hits, n, trav)
+        except Exception as e:          # the context lines must not take the headline down
+            certified = {"error": str(e)}
     d_rays.free(); d_hits.free()
     if rank == 0 and world == 1 and not args.no_extra:
         try:
-            result["extra"] = {"san_miguel_stand_in": path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0])}
+            result["extra"] = {"certified_walk": certified, "san_miguel_stand_in": path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0])}
             result["extra"]["san_miguel_stand_in_4k"] = path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 12)
             spos, saux, sidx = pt.scenes.sponza_like()
             snodes, sridx, _ = pt.build_bvh(spos, sidx, threads)
@@ -253,6 +260,48 @@ def cpu_baseline(pos, aux, ridx, nodes, d_rays, budget_s):
     return {"value": round(nsample / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": f"first {nsample} rays of rank 0's ray set, same scene, 3 repeats, median; reference-faithful CPU walk "
                       f"(clang++ -O3, {cores} threads)"}
+
+
+def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
+    """Context number: the same batch with PT_OPT_TRAVERSAL = 3, whose hits are the reference-order walk's bit for bit,
+    timed like the headline (whole calls, ordering pass included), and compared on the device with the hits of the
+    reference-order walk (= 1) and of the headline's walk."""
+    import torch
+    from pathtracer_amd import core
+
+    class _Alias:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes // 4,), "typestr": "<i4", "data": (ptr, False), "version": 3, "strides": None}
+
+    def hits_of(traversal, buf):
+        ctx.set_option(core.OPT_TRAVERSAL, traversal)
+        ctx.trace_rays_device(d_rays, n, buf)
+        ctx.synchronize()
+        return torch.as_tensor(_Alias(buf.ptr, n * 16), device=torch.device("cuda", ctx.device_id)).view(-1, 4)
+
+    other = ctx.alloc(n * 16)
+    try:
+        ctx.set_option(core.OPT_TRAVERSAL, 3)
+        for _ in range(2):
+            ctx.trace_rays_device(d_rays, n, d_hits)
+        ctx.synchronize()
+        steps = 5
+        t = time.perf_counter()
+        for _ in range(steps):
+            ctx.trace_rays_device(d_rays, n, d_hits)
+        ctx.synchronize()
+        dt = time.perf_counter() - t
+        cert = hits_of(3, d_hits)
+        ref = hits_of(1, other)
+        differ_ref = int((cert != ref).any(dim=1).sum().item())
+        fast = hits_of(headline_traversal, other)
+        differ_fast = int((fast != cert).any(dim=1).sum().item())
+    finally:
+        ctx.set_option(core.OPT_TRAVERSAL, headline_traversal)
+        other.free()
+    return {"Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "rays_whose_hit_differs_from_the_reference_order_walk": differ_ref,
+            "rays_whose_hit_differs_in_the_headline_walk": differ_fast, "rays": n}
 
 
 def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=30):
