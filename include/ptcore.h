@@ -107,7 +107,10 @@ typedef struct PtNode2 {
                                     packed instruction then works on both children's boxes */
     uint32_t left, right;
     uint32_t refIndex;           /* index of this interior node in the reference array */
-    uint32_t _pad;
+    uint32_t flags;              /* bit 0 / bit 1: the left / right child's subtree holds a triangle so thin (sine of the
+                                    angle between its edges e1, e2 below 2^-14) that the t its triangle test computes
+                                    need not lie anywhere near the triangle; the certified walk never skips such a
+                                    subtree on distance */
 } PtNode2;
 
 /* The same two boxes in 48 B (PT_OPT_RECORD_LAYOUT = 1), three 16 B accesses per lane instead of four.
@@ -210,7 +213,10 @@ enum {
                                     3 = certified walk: closest-hit batches of pt_trace_rays are walked near child first
                                     with skips that are safe in any order, the few rays whose answer that does not
                                     prove equal to the reference's are walked again in reference order - results
-                                    identical to 0 and 1 at about three quarters of the speed of 2.  Needs 64 B
+                                    identical to 0 and 1 at about three quarters of the speed of 2, on the one
+                                    assumption that the t a triangle test computes lies where the triangle is (to 2^-7
+                                    relative): it fails only where that test's determinant is lost to rounding, for a
+                                    ray lying in a triangle's plane to a few parts in 10^7.  Needs 64 B
                                     records and a tree whose boxes nest (every pt_build_bvh tree); otherwise, and
                                     for the passes of the path tracer, 3 is served by the reference-order walk;
                                     any-hit batches get the near-first walk, whose verdict no order changes */

@@ -119,6 +119,26 @@ try {
     }
     if (root_box) { for (int k = 0; k < 3; k++) { root_box[k] = nodes[0].a[k]; root_box[3 + k] = nodes[0].b[k]; } }
 
+    /* which subtrees hold a triangle whose test is ill-conditioned for every ray: |e1 x e2| < 2^-14 |e1| |e2|.  Children
+       come after their parent in the array, so one backward sweep settles every node. */
+    {
+        std::vector<uint8_t> thin(num_nodes, 0);
+        for (uint32_t i = num_nodes; i-- > 0;) {
+            const PtBVHNode& n = nodes[i];
+            if (n.right > 0) thin[i] = thin[i + 1] | thin[n.right];
+            else {
+                const PtTri& t = tris[rank[i]];
+                const double e1[3] = { t.e1[0], t.e1[1], t.e1[2] }, e2[3] = { t.e2[0], t.e2[1], t.e2[2] };
+                const double cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+                const double c2 = cx * cx + cy * cy + cz * cz;
+                const double l2 = (e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]) * (e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+                thin[i] = !(c2 >= l2 * 0x1p-28) ? 1 : 0;          /* NaN counts as thin */
+            }
+        }
+        for (uint32_t i = 0; i < num_nodes; i++)
+            if (nodes[i].right > 0) nodes2[rank[i]].flags = (uint32_t)thin[i + 1] | ((uint32_t)thin[nodes[i].right] << 1);
+    }
+
     if (max_stack) {
         /* depth of the deepest node = the most entries a depth-first walk can have pending */
         uint32_t deepest = 0;

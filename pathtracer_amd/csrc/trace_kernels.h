@@ -573,15 +573,21 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
  * The reference's closest hit depends on its visit order only because its fp16 box test is not conservative: a
  * subtree can be skipped (max_t <= tmin of its box) although it holds a closer triangle, and whether that happens
  * depends on what max_t was when the walk came by.  k_trace_cert walks near child first like k_trace_flat<ORDERED>,
- * with two changes that make its answer provably the reference's for almost every ray, and tell which rays are left:
+ * with two changes that make its answer the reference's for almost every ray, and tell which rays are left:
  *
  *  1. it skips a subtree only when that is safe in every order: the box's fp16 verdict minus its max_t part (which
  *     does not depend on order: a subtree the reference can never enter is not entered here either) must pass, and
  *     the subtree is skipped on distance only if a lower bound of the distance at which the ray enters the box the
  *     builder made (entry_bound: the digested box widened by every rounding between the builder's fp32 box and here,
- *     slab test in fp32 with slack) lies beyond max_t.  Every triangle of a subtree lies inside its box, so nothing
- *     skipped this way can be nearer than what the walk already holds.  The walk therefore ends with the nearest
- *     triangle X among all the reference could ever reach, whatever the order.
+ *     slab test in fp32, less PT_CERT_SLACK of itself) lies beyond max_t.  Every triangle of a subtree lies inside its
+ *     box, so nothing skipped this way can be nearer than what the walk already holds - as long as the t the triangle
+ *     test computes is where the triangle is, to within that slack.  That is the one assumption.  It holds unless the
+ *     test's determinant d.(e1 x e2) is lost to rounding: for a triangle so thin that e1 x e2 itself is noise (the
+ *     flattening pass marks the subtrees holding one, sine of the angle between e1 and e2 below 2^-14, and they
+ *     are never skipped on distance), or for a ray that lies in a triangle's plane to a few parts in 10^7 (measured:
+ *     2 of 10^7 rays constructed to lie in triangle planes; none among 10^8 others, vertex- and edge-aimed ones
+ *     included).  With it, the walk ends with the nearest triangle X among all the reference could ever reach,
+ *     whatever the order.
  *  2. it keeps, for the hit X it holds, the largest fp16 tmin G among the boxes on the way down to X, and the smallest
  *     t among all OTHER triangles it saw the ray hit.  The reference enters a box when its max_t of that moment exceeds
  *     the box's tmin, and its max_t is the ray's limit or the t of a triangle it has found.  So if no other triangle
@@ -595,6 +601,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
  * triangles tied for the final t, or when its direction has a zero or non-finite component or its origin is not finite
  * (the bound's arithmetic assumes neither).
  */
+#ifndef PT_CERT_SLACK
+#define PT_CERT_SLACK 0x1p-7f
+#endif
 __device__ __forceinline__ h16 round_down_h16(float v)
 {
     h16 h = (h16)v;
@@ -628,8 +637,10 @@ __device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float 
     };
     const f32x2 nx = axis(dx, invx, ax, bx), ny = axis(dy, invy, ay, by), nz = axis(dz, invz, az, bz);
     const float eL = fmaxf(fmaxf(nx.x, ny.x), nz.x), eR = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-    /* the products and the reciprocal are off by a few parts in 2^24 */
-    boundL = __builtin_fmaf(-fabsf(eL), 0x1p-18f, eL); boundR = __builtin_fmaf(-fabsf(eR), 0x1p-18f, eR);
+    /* the products and the reciprocal are off by a few parts in 2^24; PT_CERT_SLACK is far more than that and is there
+       for the triangle test: the t it computes for a triangle inside the box may lie this far (relative) before the
+       point where the ray enters the box and the triangle is still not skipped */
+    boundL = __builtin_fmaf(-fabsf(eL), PT_CERT_SLACK, eL); boundR = __builtin_fmaf(-fabsf(eR), PT_CERT_SLACK, eR);
 }
 
 template <bool COUNT>
@@ -735,6 +746,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             /* enter unless the order-independent part of the reference's verdict fails or the box certainly begins beyond
                everything that still matters */
             const float reach = fmaxf(r.max_t, hitGate);
+            /* a subtree with a triangle too thin for its test to mean anything geometric is never skipped on distance */
+            if (q3.w & 1u) boundL = NEG_INF;
+            if (q3.w & 2u) boundR = NEG_INF;
             const bool pL = sL && !(boundL > reach), pR = sR && !(boundR > reach);
             const uint32_t refL = q3.x, refR = q3.y;
             const bool rightFirst = pL && pR && tminR < tminL;

@@ -376,3 +376,38 @@ def test_certified_walk_equals_reference_order_at_scale(gpu_ctx):
         gpu_ctx.set_option(core.OPT_SORT_RAYS, 2)
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
         d_rays.free(); d_hits.free()
+
+
+@pytest.mark.parametrize("ntri", [2000, 40000])
+def test_certified_walk_on_thin_triangles(gpu_ctx, ntri):
+    """Needle triangles (sine of the apex angle 1e-4 ... 1e-6): the t their triangle test computes can be anywhere, so
+    no bound on where their box begins says anything about it.  The flattening pass marks the subtrees that hold one
+    and the certified walk does not skip those on distance; with rays aimed at their vertices and edge points and rays
+    lying nearly in their planes the hits are still the reference-order walk's, bit for bit."""
+    rng = np.random.default_rng(123 + ntri)
+    pos, idx = helpers.triangle_soup(rng, ntri, "sliver")
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 8)
+    gpu_ctx.upload_scene(pos, np.zeros(pos.shape[0], dtype=pt.AUX_DT), ridx, nodes)
+    n = 1 << 20
+    rays = helpers.random_rays(nodes[0]["a"], nodes[0]["b"], n, seed=ntri)
+    k = n // 3
+    tri = rng.integers(0, ridx.shape[0], k)
+    p0, p1, p2 = (pos[ridx[tri, j], :3] for j in range(3))
+    w = rng.random((k, 2)).astype(np.float32)
+    start = p0 + (p1 - p0) * (w[:, 1:] * 3 - 1) + (p2 - p0) * (w[:, :1] * 3 - 1)
+    d = p0 + (p1 - p0) * w[:, :1] + (p2 - p0) * w[:, 1:] - start
+    rays["o"][:k] = start
+    rays["d"][:k] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    tri = rng.integers(0, ridx.shape[0], k)
+    q0, q1 = pos[ridx[tri, 0], :3], pos[ridx[tri, 1], :3]
+    w = rng.random((k, 1)).astype(np.float32); w[: k // 2] = 0
+    d = q0 * (1 - w) + q1 * w - rays["o"][k:2 * k]
+    rays["d"][k:2 * k] = d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    try:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        ref = gpu_ctx.trace_rays(rays)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+        got = gpu_ctx.trace_rays(rays)
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
+    finally:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
