@@ -210,16 +210,17 @@ PT_API void*       pt_stream(PtContext* ctx);          /* the context's hipStrea
 enum {
     PT_OPT_TRAVERSAL      = 1,   /* 0 = reference 32 B nodes, stackless walk; 1 = PtNode2, reference visit
                                     order (results identical to 0); 2 = PtNode2, near child first (default);
-                                    3 = certified walk: closest-hit batches of pt_trace_rays are walked near child first
-                                    with skips that are safe in any order, the few rays whose answer that does not
-                                    prove equal to the reference's are walked again in reference order - results
-                                    identical to 0 and 1 at about three quarters of the speed of 2, on the one
-                                    assumption that the t a triangle test computes lies where the triangle is (to 2^-7
-                                    relative): it fails only where that test's determinant is lost to rounding, for a
-                                    ray lying in a triangle's plane to a few parts in 10^7.  Needs 64 B
-                                    records and a tree whose boxes nest (every pt_build_bvh tree); otherwise, and
-                                    for the passes of the path tracer, 3 is served by the reference-order walk;
-                                    any-hit batches get the near-first walk, whose verdict no order changes */
+                                    3 = certified walk: closest-hit rays (batches of pt_trace_rays and the closest-hit
+                                    passes of the path tracer) are walked near child first with skips that are safe in
+                                    any order, and the few rays whose answer that does not prove equal to the
+                                    reference's are walked again in reference order - results identical to 0 and 1
+                                    (hits, and with them every buffer of a frame) at about three quarters of the speed
+                                    of 2 for batches, on the one assumption that the t a triangle test computes lies
+                                    where the triangle is (to 2^-7 relative): it fails only where that test's
+                                    determinant is lost to rounding, for a ray lying in a triangle's plane to a few
+                                    parts in 10^7.  Needs 64 B records and a tree whose boxes nest (every
+                                    pt_build_bvh tree), else 3 is served by the reference-order walk; any-hit rays
+                                    get the near-first walk, whose verdict no order changes */
     PT_OPT_STALE_SLOTS    = 2,   /* 0 = zero prob of the next slot when a path ends (default); 1 = leave
                                     deeper slots as they are, as composite.frag:35-49 finds them */
     PT_OPT_RESEED         = 3,   /* 0 = seed the LCG only after a clear (launch.comp:49-50, default);

@@ -28,7 +28,10 @@ enum {
                              pass's fetch counter.  Per depth, so that nothing has to be cleared while a shadow pass
                              of an earlier depth may still be running on the second stream. */
 };
-__host__ __device__ constexpr uint32_t ctr_words(uint32_t slots) { return CTR_SHADOW + 2u * slots; }
+/* after the shadow words, two more per depth for the certified walk: closest-hit rays listed for a second walk, and that
+   walk's fetch counter */
+__host__ __device__ constexpr uint32_t ctr_flag_base(uint32_t slots) { return CTR_SHADOW + 2u * slots; }
+__host__ __device__ constexpr uint32_t ctr_words(uint32_t slots) { return CTR_SHADOW + 4u * slots; }
 
 struct FrameArgs {
     PtShaderConstants c;

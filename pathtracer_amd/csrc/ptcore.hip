@@ -74,6 +74,7 @@ struct FramePipe {
     PtRayStackSlot* dStack = nullptr; uint32_t* dJobs[2] = { nullptr, nullptr }; int curJobs = 0;
     PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow[2] = { nullptr, nullptr };
     uint32_t* dCtr = nullptr; unsigned long long* dRayCounts = nullptr;
+    uint32_t* dFlag = nullptr;                            /* certified walk: jobs listed for the second walk (allocated on first use) */
 };
 
 struct PtContext {
@@ -91,6 +92,7 @@ struct PtContext {
     uint32_t V = 0, T = 0, N = 0, L = 0, maxStack = 0, overflowEntries = 0;
     uint64_t overflowLanes = 0; int overflowAreas = 0;
     float rootBox[6] = {0}; float rootC[3] = {0}; uint16_t rootH[6] = {0};
+    float lastC[3] = {0}; uint16_t lastH[6] = {0};        /* box digest of the reference array's last node */
 
     /* per-resolution (bindings 5,6,9,10) */
     uint32_t W = 0, H = 0, slots = 0;
@@ -134,7 +136,7 @@ void free_scene(PtContext* c)
 void free_pipe_buffers(FramePipe& p)
 {
     dfree(p.dStack); dfree(p.dJobs[0]); dfree(p.dJobs[1]); dfree(p.dHitRecs); dfree(p.dShadow[0]); dfree(p.dShadow[1]);
-    dfree(p.dCtr); dfree(p.dRayCounts);
+    dfree(p.dCtr); dfree(p.dRayCounts); dfree(p.dFlag);
     p.ready = false; p.curJobs = 0;
     p.shadowBusy[0] = p.shadowBusy[1] = p.shade0Pending = p.donePending = false;
 }
@@ -180,6 +182,8 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     a.leafRef = c->dLeafRef; a.lastLeaf = c->lastLeaf;
     for (int k = 0; k < 3; k++) a.rootC[k] = c->rootC[k];
     for (int k = 0; k < 6; k++) a.rootH[k] = c->rootH[k];
+    for (int k = 0; k < 3; k++) a.lastC[k] = c->lastC[k];
+    for (int k = 0; k < 6; k++) a.lastH[k] = c->lastH[k];
     a.rootRef = (c->T == 1) ? PT_LEAF_BIT : 0u;
     a.overflow = c->dOverflow; a.overflowEntries = c->overflowEntries;
     a.refillMin = (uint32_t)c->optRefillMin; a.claimChunk = (uint32_t)c->optClaimChunk;
@@ -196,10 +200,11 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
     dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
     a.refillMin = (uint32_t)refill_min(ctx, shape);
-    /* 3 (certified walk) exists for closest-hit batches of pt_trace_rays, which launches it itself; any-hit batches get
-       the near-first walk (their verdict does not depend on the order), every other pass the reference-order walk */
+    /* 3 (certified walk): closest-hit passes launch k_trace_cert themselves (launch_cert) and come here for the second
+       walk of the rays it listed, in reference order; any-hit passes get the near-first walk, whose verdict no order
+       changes; 48 B records and trees whose boxes do not nest get the reference-order walk throughout */
     int trav = ctx->optTraversal;
-    if (trav == 3) trav = (MODE == MODE_RAYS && ANYHIT) ? 2 : 1;
+    if (trav == 3) trav = ANYHIT ? 2 : 1;
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
@@ -225,6 +230,26 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
 /* Every entry point that touches the device starts here: allocations go to the current device, and a host thread that
  * drives several contexts has whichever device it used last. */
 int enter(PtContext* ctx) { HIPCHK(hipSetDevice(ctx->device)); return 0; }
+
+/* The certified walk over the batch or job list `a` describes, then the reference-order walk over the rays it listed.
+ * flag: room for one index per ray; ctr: two zeroed words (count of listed rays, the second walk's fetch counter). */
+template <int MODE>
+int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, int area, uint32_t* flag, uint32_t* ctr)
+{
+    if (int rc = ensure_overflow(ctx)) return rc;
+    a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
+    a.overflowEntries = ctx->overflowEntries;
+    a.flagList = flag; a.flagCount = ctr;
+    const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
+    a.refillMin = (uint32_t)refill_min(ctx, shape);
+    dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
+    if (count) hipLaunchKernelGGL((k_trace_cert<MODE, true>), grid, block, 0, stream, a);
+    else hipLaunchKernelGGL((k_trace_cert<MODE, false>), grid, block, 0, stream, a);
+    HIPCHK(hipGetLastError());
+    TraceArgs b = a;
+    b.order = flag; b.countPtr = ctr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
+    return launch_trace<MODE, false>(ctx, b, count, stream, area);        /* traversal 3 maps to the reference-order walk there */
+}
 
 int check_scene(PtContext* ctx) { return ctx->T ? 0 : ctx->fail(-2, "no scene uploaded (call pt_scene_upload first)"); }
 int check_frame(PtContext* ctx)
@@ -454,6 +479,10 @@ try {
         ctx->rootC[k] = (ctx->rootBox[k] + ctx->rootBox[3 + k]) * 0.5f;
         _Float16 ha = (_Float16)(ctx->rootBox[k] - ctx->rootC[k]), hb = (_Float16)(ctx->rootBox[3 + k] - ctx->rootC[k]);
         memcpy(&ctx->rootH[k], &ha, 2); memcpy(&ctx->rootH[3 + k], &hb, 2);
+        const PtBVHNode& last = nodes[N - 1];
+        ctx->lastC[k] = (last.a[k] + last.b[k]) * 0.5f;
+        _Float16 la = (_Float16)(last.a[k] - ctx->lastC[k]), lb = (_Float16)(last.b[k] - ctx->lastC[k]);
+        memcpy(&ctx->lastH[k], &la, 2); memcpy(&ctx->lastH[3 + k], &lb, 2);
     }
 
     HIPCHK(hipMalloc((void**)&ctx->dPositions, (size_t)V * 16));
@@ -598,6 +627,11 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
         dim3 grid(ctx->W / 8, ctx->H / 8), block(64);
         hipLaunchKernelGGL(k_trace_ref_speculative, grid, block, 0, p.stream, a, ctx->W, ctx->H);
         HIPCHK(hipGetLastError());
+    } else if (ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest) {
+        if (!p.dFlag) HIPCHK(hipMalloc((void**)&p.dFlag, (size_t)ctx->W * ctx->H * 4));
+        uint32_t* flagCtr = p.dCtr + ctr_flag_base(ctx->slots) + 2 * depth;
+        if (!overlapped) HIPCHK(hipMemsetAsync(flagCtr, 0, 2 * 4, p.stream));          /* overlapped: k_launch cleared them */
+        if (int rc = launch_cert<MODE_JOBS>(ctx, a, false, p.stream, 2 * p.index, p.dFlag, flagCtr)) return rc;
     } else {
         if (int rc = launch_trace<MODE_JOBS, false>(ctx, a, false, p.stream, 2 * p.index)) return rc;
     }
@@ -873,19 +907,7 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = 0;
     if (certified) {
-        /* first every ray by the certified walk, which lists the few it cannot vouch for; then those by the reference-order walk */
-        if ((rc = ensure_overflow(ctx))) return rc;
-        a.overflow = ctx->dOverflow; a.overflowEntries = ctx->overflowEntries;
-        a.flagList = ctx->dFlagList; a.flagCount = ctx->dFlagCtr;
-        const int shape = a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH;
-        a.refillMin = (uint32_t)refill_min(ctx, shape);
-        dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
-        if (stats) hipLaunchKernelGGL((k_trace_cert<true>), grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL((k_trace_cert<false>), grid, block, 0, ctx->stream, a);
-        HIPCHK(hipGetLastError());
-        TraceArgs b = a;
-        b.order = ctx->dFlagList; b.countPtr = ctx->dFlagCtr; b.fetchCounter = ctx->dFlagCtr + 1; b.flagList = nullptr; b.flagCount = nullptr;
-        rc = launch_trace<MODE_RAYS, false>(ctx, b, stats != nullptr, ctx->stream, 0);       /* traversal 3 maps to the reference-order walk there */
+        rc = launch_cert<MODE_RAYS>(ctx, a, stats != nullptr, ctx->stream, 0, ctx->dFlagList, ctx->dFlagCtr);
     } else {
         rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);
     }

@@ -72,6 +72,7 @@ struct TraceArgs {
     const uint32_t*  leafRef;        /* 48 B records: reference node index of each leaf */
     uint32_t         lastLeaf;       /* 48 B records: triangle index of the leaf that is the reference array's last node */
     float            rootC[3]; uint16_t rootH[6]; uint32_t rootRef;
+    float            lastC[3]; uint16_t lastH[6];          /* the same digest of the box of the reference array's last node */
     uint2*           overflow;       /* [entry][global lane] spill area of the LDS stacks */
     uint32_t         overflowEntries;
     /* work */
@@ -428,14 +429,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         if (nIdle == 64 && pool.exhausted()) break;
         bool fresh = false;
         RayWords w;
-        if (MODE == MODE_RAYS && pend) {        /* the index fetched a turn ago names this lane's next ray */
+        if (MODE != MODE_SHADOW && pend) {      /* the index fetched a turn ago names this lane's next ray */
             id = pendIdx; pend = false;
             fresh = issue_ray<MODE>(a, id, w);
         }
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
             if (canTake && nid != ~0ull) {
-                if (MODE == MODE_RAYS && a.order) { pendIdx = a.order[nid]; pend = true; }     /* used next turn: no wait here */
+                if (MODE != MODE_SHADOW && a.order) { pendIdx = a.order[nid]; pend = true; }   /* used next turn: no wait here */
                 else { id = nid; fresh = issue_ray<MODE>(a, id, w); }
             }
         }
@@ -643,7 +644,7 @@ __device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float 
     boundL = __builtin_fmaf(-fabsf(eL), PT_CERT_SLACK, eL); boundR = __builtin_fmaf(-fabsf(eR), PT_CERT_SLACK, eR);
 }
 
-template <bool COUNT>
+template <int MODE, bool COUNT>      /* MODE_RAYS or MODE_JOBS */
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
 {
     __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
@@ -662,8 +663,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
     float invx = 0, invy = 0, invz = 0;
     uint32_t cur = 0; int sp = 0;
-    bool hit = false, tie = false;
+    bool hit = false, tie = false, nearLast = false;
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
+    float alpha = 0, beta = 0, gamma = 0;
     float pathGate = 0, hitGate = 0;      /* largest fp16 tmin on the way to the current record / to the hit held */
     float limit0 = 0, otherT = 0;         /* the ray's own max_t; smallest t of any other triangle the ray was seen to hit */
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     auto flag_ray = [&]() { a.flagList[atomicAdd(a.flagCount, 1u)] = (uint32_t)id; };
 
     auto start_ray = [&](const RayWords& w) {
-        finish_ray<MODE_RAYS>(w, r, exclude, tag);
+        finish_ray<MODE>(w, r, exclude, tag);
         if (COUNT) { nRay++; nBox++; }
         hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
         limit0 = r.max_t; otherT = __builtin_huge_valf();
@@ -686,10 +688,18 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
                             (r.d.x - r.d.x) + (r.d.y - r.d.y) + (r.d.z - r.d.z);
         const bool walkable = probe == 0.0f && invx != 0.0f && invy != 0.0f && invz != 0.0f;
         float ftmin;
+        if (MODE == MODE_JOBS) {
+            /* what the shade pass is told besides the hit - whether the reference's walk went on into the last node of
+               its array (intersections.glsl:109-113) - depends on that walk's max_t when it got there.  It cannot have
+               gone in if the order-independent part of that node's box test fails, which is the case for all but a
+               few rays in a million; those few take the second walk */
+            nearLast = box_static(r, a.lastC[0], a.lastC[1], a.lastC[2], hfrombits(a.lastH[0]), hfrombits(a.lastH[1]), hfrombits(a.lastH[2]),
+                                  hfrombits(a.lastH[3]), hfrombits(a.lastH[4]), hfrombits(a.lastH[5]), ftmin);
+        }
         bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
-        if (!walkable) { flag_ray(); store_result<MODE_RAYS>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0); }
+        if (!walkable) { flag_ray(); store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0); }
         else if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }          /* the root's test is the reference's own: it comes first in every order */
-        else store_result<MODE_RAYS>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
+        else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
     };
 
     for (;;) {
@@ -699,12 +709,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         if (nIdle == 64 && pool.exhausted()) break;
         bool fresh = false;
         RayWords w;
-        if (pend) { id = pendIdx; pend = false; fresh = issue_ray<MODE_RAYS>(a, id, w); }
+        if (pend) { id = pendIdx; pend = false; fresh = issue_ray<MODE>(a, id, w); }
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
             if (canTake && nid != ~0ull) {
                 if (a.order) { pendIdx = a.order[nid]; pend = true; }
-                else { id = nid; fresh = issue_ray<MODE_RAYS>(a, id, w); }
+                else { id = nid; fresh = issue_ray<MODE>(a, id, w); }
             }
         }
 
@@ -730,7 +740,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             if (t >= r.min_t && t <= limit0 && al >= 0.0f && be >= 0.0f && ga >= 0.0f) {
                 if (t <= r.max_t) {                         /* the reference's acceptance: replaces the hit held */
                     if (hit) { if (t == r.max_t) tie = true; otherT = fminf(otherT, r.max_t); }
-                    r.max_t = t; hit = true; hitGate = pathGate;
+                    r.max_t = t; hit = true; hitGate = pathGate; alpha = al; beta = be; gamma = ga;
                     hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w;
                 } else otherT = fminf(otherT, t);
             }
@@ -780,8 +790,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         }
 
         if (done) {
-            if (hit && (tie || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
-            store_result<MODE_RAYS>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, 0, 0, 0, 0);
+            if (hit && (tie || nearLast || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
+            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
             active = false;
         }
         }   /* if (active) */

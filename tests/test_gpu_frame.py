@@ -58,7 +58,7 @@ def _compare(ctx, fr, strict=True, live_slots_only=False):
 
 
 @pytest.mark.parametrize("name,cam", [("bunny", BUNNY_CAM), ("monkey", {})])
-@pytest.mark.parametrize("trav", [core.TRAVERSAL_FLAT, core.TRAVERSAL_REFERENCE_LAYOUT])
+@pytest.mark.parametrize("trav", [core.TRAVERSAL_FLAT, core.TRAVERSAL_REFERENCE_LAYOUT, core.TRAVERSAL_CERTIFIED])
 def test_frames_match_oracle(gpu_ctx, oracle_lib, request, name, cam, trav):
     model = request.getfixturevalue(name)
     W, H, NR = 256, 144, 4
@@ -502,3 +502,57 @@ def test_contexts_give_their_device_memory_back(bunny):
         cycle()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 32 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory not returned"
+
+
+def test_certified_walk_frames(gpu_ctx, oracle_lib, monkey):
+    """PT_OPT_TRAVERSAL = 3 in the frame pipeline: closest-hit passes by the certified walk plus the second walk of the
+    jobs it lists, shadow passes near child first.  Every buffer equals the oracle's: several frames in flight, dispatch
+    site by dispatch site, and on a random soup with glass."""
+    W, H, NR = 160, 96, 5
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 3)
+    try:
+        c0 = _consts(monkey, W, H, NR, 1, {})
+        gpu_ctx.set_constants(c0)
+        gpu_ctx.render_samples(1, 5)
+        for frame in range(1, 6):
+            oracle.render_frame(osc, fr, _consts(monkey, W, H, NR, frame, {}), mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        _compare(gpu_ctx, fr, live_slots_only=True)
+        # dispatch sites one by one (the passes then run one after another on one stream and rewrite jobs in place)
+        osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+        c = _consts(monkey, W, H, NR, 1, {})
+        gpu_ctx.set_constants(c)
+        gpu_ctx.launch(); oracle.launch(osc, fr, c)
+        for d in range(NR):
+            gpu_ctx.trace(d)
+            oracle.trace(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+            slots, _ = gpu_ctx.readback_raystack()
+            assert np.array_equal(slots.view(np.uint8), fr.stack.view(np.uint8)), f"depth {d}"
+        gpu_ctx.resolve_accumulate(); oracle.composite(fr, c)
+        _compare(gpu_ctx, fr)
+        # a soup: random colours, glass, normals unrelated to the winding
+        rng = np.random.default_rng(9)
+        n = 200
+        pos = np.ones((3 * n, 4), np.float32)
+        pos[:, :3] = rng.uniform(-1, 1, (3 * n, 3)).astype(np.float32); pos[:, 1] += 1.0
+        idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        aux = np.zeros(3 * n, dtype=pt.AUX_DT)
+        aux["normal"] = rng.normal(0, 1, (3 * n, 3)).astype(np.float32)
+        aux["color"] = rng.integers(0, 256, (3 * n, 4), dtype=np.uint8)
+        aux["color"][:, 3] = np.where(rng.random(3 * n) < 0.3, 0, 255)
+        nodes, ridx, _ = pt.build_bvh(pos, idx, 1)
+        model = dict(positions=pos, aux=aux, indices=ridx, nodes=nodes)
+        osc, fr = _setup(gpu_ctx, model, W, H, NR)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+        cam = dict(focus_center=(0.0, 1.0, 0.0), orbit_height=1.2, orbit_radius=3.0, orbit_angle=0.7)
+        for frame in (1, 2, 3):
+            c = _consts(model, W, H, NR, frame, cam)
+            gpu_ctx.set_constants(c)
+            gpu_ctx.render_sample(frame)
+            oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+            _compare(gpu_ctx, fr)
+    finally:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
