@@ -239,7 +239,7 @@ enum {
                                     tracing it (results are stored under the rays' own indices and do not change):
                                     0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
     PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 4): the ordering grid has 2^bits cells per axis */
-    PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..4 (default 3): frames pt_render_samples keeps in flight, each on its own ray
+    PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and pair of streams; results do not depend on it */
 };
 PT_API int pt_set_option(PtContext* ctx, int option, int value);

@@ -57,7 +57,7 @@ bool load_nccl(std::string& err)
 
 }  // namespace
 
-enum { PT_MAX_PIPES = 4 };
+enum { PT_MAX_PIPES = 8 };
 
 /* Everything one frame in flight owns: its ray stack, job lists, hit records, shadow queues, counters, and the two
  * streams its passes run on.  Pipe 0 serves the dispatch-site API and pt_render_sample; pt_render_samples deals
@@ -405,7 +405,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0 or 1"); ctx->optRecordLayout = value; return 0;
         case PT_OPT_SORT_BITS: if (value < 1 || value > 4) return ctx->fail(-1, "PT_OPT_SORT_BITS must be 1..4"); ctx->optSortBits = value; return 0;
         case PT_OPT_SORT_RAYS: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SORT_RAYS must be 0, 1 or 2"); ctx->optSortRays = value; return 0;
-        case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..4"); ctx->optFramesInFlight = value; return 0;
+        case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
 }
