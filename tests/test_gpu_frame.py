@@ -298,7 +298,7 @@ def test_tonemap_and_frame_dump(gpu_ctx, oracle_lib, monkey, tmp_path):
     assert (tmp_path / "monkey.ppm").stat().st_size == len(f"P6\n{W} {H}\n255\n") + W * H * 3
 
 
-@pytest.mark.parametrize("in_flight", [1, 2, 3, 4])
+@pytest.mark.parametrize("in_flight", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("reseed", [0, 1])
 def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_flight, reseed):
     """pt_render_samples with several frames in flight leaves the ray stack, the current image and the accumulation of
