@@ -337,6 +337,11 @@ PT_API int   pt_device_free(PtContext* ctx, void* p);
 PT_API int   pt_copy_to_host(PtContext* ctx, void* dst, const void* d_src, size_t bytes);
 PT_API int   pt_copy_to_device(PtContext* ctx, void* d_dst, const void* src, size_t bytes);
 
+
+/* Self-test with no counterpart in the reference: checks on the device, over num_cases random boxes and rays, that the
+ * entry-distance bound the certified walk (PT_OPT_TRAVERSAL = 3) skips subtrees by never exceeds the true entry distance
+ * (fp64) into the box the digest was made from.  *checked = cases in which the ray reaches the box, *violations must be 0. */
+PT_API int pt_selftest_entry_bound(PtContext* ctx, uint64_t seed, uint64_t num_cases, uint64_t* checked, uint64_t* violations);
 /* Time of the last traversal launch in milliseconds, measured with HIP events on the
  * context's stream (closest-hit launch of pt_trace_rays, or the sum over a pt_render_sample). */
 PT_API float pt_last_kernel_ms(PtContext* ctx);

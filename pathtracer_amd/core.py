@@ -89,6 +89,7 @@ def _load():
         "pt_get_option": (i32, [vp, i32, C.POINTER(i32)]),
         "pt_scene_upload": (i32, [vp, vp, u32, vp, vp, u32, vp, u32, vp, u32, vp]),
         "pt_resize": (i32, [vp, u32, u32, u32]),
+        "pt_selftest_entry_bound": (i32, [vp, u64, u64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "pt_set_constants": (i32, [vp, vp]),
         "pt_clear_accumulation": (i32, [vp]),
         "pt_launch": (i32, [vp]),
@@ -412,6 +413,12 @@ class PathTracer:
         st = np.zeros(4, dtype=np.uint64) if want_stats else None
         self._chk(self._L.pt_trace_rays_host(self._h, _p(rays), rays.shape[0], int(any_hit), _p(hits), _p(st)))
         return (hits, st) if want_stats else hits
+
+    def selftest_entry_bound(self, num_cases, seed=1):
+        """(cases in which the ray reaches the box, violations of bound <= true entry distance); see ptcore.h."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._chk(self._L.pt_selftest_entry_bound(self._h, seed, num_cases, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def last_kernel_ms(self):
         return float(self._L.pt_last_kernel_ms(self._h))

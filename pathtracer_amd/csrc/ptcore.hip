@@ -988,6 +988,21 @@ PT_API int pt_copy_to_device(PtContext* ctx, void* d_dst, const void* src, size_
     return 0;
 }
 
+PT_API int pt_selftest_entry_bound(PtContext* ctx, uint64_t seed, uint64_t num_cases, uint64_t* checked, uint64_t* violations)
+{
+    if (!ctx || !checked || !violations) return -1;
+    if (int rc = enter(ctx)) return rc;
+    if (num_cases == 0 || num_cases > 0xFFFFFF00ull) return ctx->fail(-1, "pt_selftest_entry_bound: 1 .. 2^32-256 cases");
+    HIPCHK(hipMemsetAsync(ctx->dStats, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_entry_bound, dim3((uint32_t)((num_cases + 255) / 256)), dim3(256), 0, ctx->stream, seed, num_cases, ctx->dStats);
+    HIPCHK(hipGetLastError());
+    unsigned long long out[2] = { 0, 0 };
+    HIPCHK(hipMemcpyAsync(out, ctx->dStats, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *checked = out[0]; *violations = out[1];
+    return 0;
+}
+
 PT_API float pt_last_kernel_ms(PtContext* ctx)
 {
     if (!ctx) return -1.0f;

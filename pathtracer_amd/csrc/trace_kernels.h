@@ -802,3 +802,76 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
     }
 }
+
+/* Self-test of entry_bound, the lemma the certified walk rests on: for random fp32 boxes [a, b] (sizes and offsets over
+ * twenty octaves, including half extents that are fp16 subnormals or beyond the fp16 range) digested exactly as the
+ * flattening pass digests them, and random rays (starting inside, outside, far away; directions down to 1e-6 in a
+ * component), the bound never exceeds the distance at which the ray enters [a, b], computed here in fp64.  Counts the
+ * cases checked (the ray does reach the box) and the violations. */
+__device__ __forceinline__ uint64_t selftest_rand(uint64_t& s)
+{
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void k_selftest_entry_bound(uint64_t seed, uint64_t n, unsigned long long* out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + i * 0xD1B54A32D192ED03ull;
+    auto uni = [&]() { return (float)(selftest_rand(s) >> 40) * (1.0f / 16777216.0f); };
+    /* two boxes (the two halves of one record), one ray */
+    float a[2][3], b[2][3], o[3], d[3];
+    const float offScale = __builtin_exp2f(uni() * 20.0f - 8.0f);            /* where the boxes sit: 2^-8 .. 2^12 */
+    for (int k = 0; k < 2; k++) {
+        const float size = __builtin_exp2f(uni() * 30.0f - 20.0f);           /* half extents 2^-20 .. 2^10, times up to 2^7 below */
+        for (int x = 0; x < 3; x++) {
+            const float c = (uni() * 2.0f - 1.0f) * offScale, h = size * (uni() < 0.1f ? 128.0f * uni() : uni()) + 6e-5f;
+            a[k][x] = c - h; b[k][x] = c + h * (0.5f + uni());
+        }
+    }
+    const int pick = (int)(selftest_rand(s) & 1);
+    const float where = uni();
+    for (int x = 0; x < 3; x++) {
+        const float mid = (a[pick][x] + b[pick][x]) * 0.5f, half = (b[pick][x] - a[pick][x]) * 0.5f;
+        const float spread = where < 0.3f ? 0.9f : (where < 0.7f ? 4.0f : 300.0f);     /* inside, near, far */
+        o[x] = mid + (uni() * 2.0f - 1.0f) * half * spread + (where >= 0.7f ? (uni() * 2.0f - 1.0f) * offScale : 0.0f);
+    }
+    {
+        float z = 1.0f - 2.0f * uni(), phi = 6.2831853f * uni(), rr = __builtin_sqrtf(fmaxf(0.0f, 1.0f - z * z));
+        d[0] = rr * cosf(phi); d[1] = rr * sinf(phi); d[2] = z;
+        if (uni() < 0.2f) d[(int)(selftest_rand(s) % 3)] *= 1e-6f * (0.01f + uni());           /* nearly parallel to a slab */
+        if (uni() < 0.3f) {        /* aimed at a point of the picked box, so that most cases count */
+            float len = 0;
+            for (int x = 0; x < 3; x++) { d[x] = a[pick][x] + (b[pick][x] - a[pick][x]) * uni() - o[x]; len += d[x] * d[x]; }
+            len = __builtin_sqrtf(len);
+            for (int x = 0; x < 3; x++) d[x] = len > 0 ? d[x] / len : (x == 0 ? 1.0f : 0.0f);
+        }
+    }
+    if (d[0] == 0.0f || d[1] == 0.0f || d[2] == 0.0f) return;
+    /* digest as scene_prep.cpp does, bound as k_trace_cert does */
+    f32x2 c[3], dd[3]; h16x2 ha[3], hb[3];
+    for (int x = 0; x < 3; x++) {
+        float cc[2];
+        for (int k = 0; k < 2; k++) cc[k] = (a[k][x] + b[k][x]) * 0.5f;
+        c[x] = { cc[0], cc[1] };
+        ha[x] = { (h16)(a[0][x] - cc[0]), (h16)(a[1][x] - cc[1]) };
+        hb[x] = { (h16)(b[0][x] - cc[0]), (h16)(b[1][x] - cc[1]) };
+        dd[x] = { cc[0] - o[x], cc[1] - o[x] };
+    }
+    float boundL, boundR;
+    entry_bound(dd[0], dd[1], dd[2], 1.0f / d[0], 1.0f / d[1], 1.0f / d[2], ha[0], ha[1], ha[2], hb[0], hb[1], hb[2], boundL, boundR);
+    for (int k = 0; k < 2; k++) {
+        double enter = -1e300, leave = 1e300;
+        for (int x = 0; x < 3; x++) {
+            const double t0 = ((double)a[k][x] - (double)o[x]) / (double)d[x], t1 = ((double)b[k][x] - (double)o[x]) / (double)d[x];
+            enter = fmax(enter, fmin(t0, t1)); leave = fmin(leave, fmax(t0, t1));
+        }
+        if (!(enter <= leave)) continue;                                  /* the ray does not reach this box: nothing is claimed */
+        atomicAdd(out + 0, 1ull);
+        const float bound = k == 0 ? boundL : boundR;
+        if (!((double)bound <= enter)) atomicAdd(out + 1, 1ull);         /* a NaN bound skips nothing, but would hide a mistake: counted too */
+    }
+}

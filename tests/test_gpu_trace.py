@@ -411,3 +411,14 @@ def test_certified_walk_on_thin_triangles(gpu_ctx, ntri):
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
     finally:
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+
+
+def test_entry_bound_never_exceeds_the_true_entry_distance(gpu_ctx):
+    """The lemma under the certified walk, checked where it is computed: 2^26 random boxes and rays on the device, the
+    bound against the fp64 entry distance into the builder's box."""
+    total = 0
+    for seed in (1, 2, 3, 4):
+        checked, violations = gpu_ctx.selftest_entry_bound(1 << 24, seed=seed)
+        assert violations == 0, f"{violations} of {checked} cases: bound beyond the true entry distance"
+        total += checked
+    assert total > (1 << 24)            # the ray reaches the box in a good share of the cases
