@@ -586,7 +586,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
  *     test's determinant d.(e1 x e2) is lost to rounding: for a triangle so thin that e1 x e2 itself is noise (the
  *     flattening pass marks the subtrees holding one, sine of the angle between e1 and e2 below 2^-14, and they
  *     are never skipped on distance), or for a ray that lies in a triangle's plane to a few parts in 10^7 (measured:
- *     2 of 10^7 rays constructed to lie in triangle planes; none among 10^8 others, vertex- and edge-aimed ones
+ *     2 to 6 of 10^7 rays constructed to lie in triangle planes; none among 10^8 others, vertex- and edge-aimed ones
  *     included).  With it, the walk ends with the nearest triangle X among all the reference could ever reach,
  *     whatever the order.
  *  2. it keeps, for the hit X it holds, the largest fp16 tmin G among the boxes on the way down to X, and the smallest

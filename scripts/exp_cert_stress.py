@@ -9,7 +9,7 @@ from pathtracer_amd import core
 import helpers
 
 ctx = pt.PathTracer(0)
-rng = np.random.default_rng(123)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 123)
 total = bad = 0
 for kind in ("sliver", "flat", "unit", "offset", "huge"):
     for ntri in (2000, 40000):
