@@ -217,6 +217,7 @@ def main():
         try:
             result["extra"] = {"certified_walk": certified, "san_miguel_stand_in": path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0])}
             result["extra"]["san_miguel_stand_in_4k"] = path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 12)
+            result["extra"]["san_miguel_stand_in_certified_frames"] = certified_frames(ctx, ridx.shape[0], nodes.shape[0])
             spos, saux, sidx = pt.scenes.sponza_like()
             snodes, sridx, _ = pt.build_bvh(spos, sidx, threads)
             ctx.upload_scene(spos, saux, sridx, snodes, pt.default_lights(), pt.load_blue_noise())
@@ -302,6 +303,35 @@ def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
     return {"Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "rays_whose_hit_differs_from_the_reference_order_walk": differ_ref,
             "rays_whose_hit_differs_in_the_headline_walk": differ_fast, "rays": n}
+
+
+def certified_frames(ctx, num_triangles, num_nodes):
+    """Context number: the path tracer under PT_OPT_TRAVERSAL = 3 at 1080p x 8 bounces, and whether its accumulation after
+    six frames from a cleared buffer is, byte for byte, that of the reference-order walk (= 1) and of the default (= 2)."""
+    import pathtracer_amd as pt
+    from pathtracer_amd import core
+    W, H, NR, nf = 1920, 1080, 8, 12
+    ctx.resize(W, H, NR)
+    ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
+    acc = {}
+    try:
+        for trav in (3, 1, 2):
+            ctx.set_option(core.OPT_TRAVERSAL, trav)
+            ctx.clear_accumulation()
+            ctx.render_samples(1, 6)
+            acc[trav] = ctx.readback_accumulation()
+        ctx.set_option(core.OPT_TRAVERSAL, 3)
+        ctx.synchronize()
+        t = time.perf_counter()
+        ctx.render_samples(7, nf)
+        ctx.synchronize()
+        dt = time.perf_counter() - t
+    finally:
+        ctx.set_option(core.OPT_TRAVERSAL, 2)
+    differ = lambda a, b: int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())
+    return {"spp_per_s_1080p": round(nf / dt, 2), "frames_in_flight": ctx.get_option(core.OPT_FRAMES_IN_FLIGHT),
+            "pixels_differing_from_the_reference_order_walk_after_6_frames": differ(acc[3], acc[1]),
+            "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
 
 
 def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=30):
