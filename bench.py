@@ -31,9 +31,15 @@ import time
 import numpy as np
 
 # The path tracer keeps three frames in flight on six streams; with four hardware queues per process (HIP's default,
-# and what the test boxes export) streams share queues and wait on each other: 183 against 199 spp/s at 1080p.  The
-# setting is read when the HIP runtime starts, hence before torch is imported.  PT_HW_QUEUES overrides.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("PT_HW_QUEUES", "8")
+# and what the test boxes export) streams share queues and wait on each other: about a tenth fewer spp/s at 1080p than
+# with eight.  The setting is read when the HIP runtime starts, hence before torch is imported.  A value the
+# environment already exports is what a C++ host linking the library would get too, so it is kept; PT_HW_QUEUES
+# overrides it, and the effective value is printed with the result (config.hw_queues_per_process).  The headline
+# (one traversal kernel on one stream) does not depend on it.
+if "PT_HW_QUEUES" in os.environ:
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["PT_HW_QUEUES"]
+else:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -103,7 +109,9 @@ def main():
     nprefix = min(n, 1 << 20)
     st = ctx.trace_rays_device(d_rays, nprefix, d_hits, want_stats=True)
     box_per_ray, tri_per_ray, rec_per_ray = (float(st[k]) / nprefix for k in range(3))
-    bytes_per_ray = 32.0 + 16.0 + 64.0 * rec_per_ray
+    bytes_per_ray = 32.0 + 16.0 + 64.0 * rec_per_ray          # records are counted in 64 B units, whatever the layout
+    kernel_name = {0: "k_trace_ref<MODE_RAYS>", 3: "k_trace_cert<MODE_RAYS>"}.get(
+        args.traversal if args.traversal >= 0 else ctx.get_option(core.OPT_TRAVERSAL), "k_trace_flat<MODE_RAYS>")
 
     def barrier():
         ctx.synchronize()
@@ -140,19 +148,24 @@ def main():
 
     total_rays = float(n) * world * args.steps
     mrays = total_rays / elapsed / 1e6
-    achieved = bytes_per_ray * n / (kernel_ms * 1e-3) / 1e9
+    requested = bytes_per_ray * n / (kernel_ms * 1e-3) / 1e9
 
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (bench.py cannot
-    # collect counters on itself); profiles/traffic.json holds the latest, keyed by workload
-    traffic = None
-    trav = args.traversal if args.traversal >= 0 else 2
+    # collect counters on itself); profiles/traffic.json holds the latest, keyed by workload and record layout
+    traffic, l2_hit, traffic_src = None, None, None
+    trav = args.traversal if args.traversal >= 0 else ctx.get_option(core.OPT_TRAVERSAL)
+    layout = ctx.get_option(core.OPT_RECORD_LAYOUT)
     try:
         for rec in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["records"]:
             k = rec["key"]
-            if k["triangles"] == int(ridx.shape[0]) and k["rays_per_gpu"] == n and k["traversal"] == trav:
-                traffic = rec["traffic_bytes_per_launch"]
+            if (k["triangles"] == int(ridx.shape[0]) and k["rays_per_gpu"] == n and k["traversal"] == trav
+                    and k.get("record_layout", 0) == layout):
+                traffic, l2_hit, traffic_src = rec["traffic_bytes_per_launch"], rec.get("l2_hit_rate"), rec.get("source")
     except (OSError, KeyError, ValueError):
         pass
+    # the roofline figure is what crosses the fabric per unit of kernel time; the bytes the walk asks for (most of
+    # which the L2 serves when the batch is traced in origin-cell order) are reported beside it, not against the peak
+    hbm_gbs = traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None
 
     result = {
         "metric": "incoherent closest-hit Mrays/s",
@@ -173,9 +186,10 @@ def main():
             "rays_per_gpu": n,
             "triangles": int(ridx.shape[0]),
             "bvh_nodes": int(nodes.shape[0]),
-            "traversal": {0: "reference 32 B nodes, stackless", 1: "flattened 64 B records, reference visit order",
-                          2: "flattened 64 B records, near child first",
-                          3: "flattened 64 B records, certified walk (hits identical to the reference order's)"}[trav],
+            "traversal": {0: "reference 32 B nodes, stackless", 1: "flattened records, reference visit order",
+                          2: "flattened records, near child first",
+                          3: "flattened records, certified walk (hits identical to the reference order's)"}[trav],
+            "record_layout": {0: "64 B two-box records", 1: "48 B two-box records", 2: "128 B two-level treelet records"}.get(layout, layout),
             "ray_ordering": "each batch is traced in the order of its origin cells (16^3 grid over the scene box); the order is "
                             "built inside the timed step, results are stored under the rays' own indices",
             "other_kernels_ms_per_step": round(elapsed / args.steps * 1e3 - kernel_ms, 3),
@@ -187,20 +201,23 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "achieved": round(achieved, 1),
+            "achieved": round(hbm_gbs, 1) if hbm_gbs else None,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac": round(hbm_gbs / HBM_PEAK_GBS, 4) if hbm_gbs else None,
             "traffic": traffic,
-            "kernel": "k_trace_flat<MODE_RAYS> (closest hit)",
+            "traffic_source": traffic_src,
+            "l2_hit_rate": l2_hit,
+            "requested_GBps": round(requested, 1),
+            "kernel": f"{kernel_name} (closest hit)",
             "kernel_ms": round(kernel_ms, 3),
             "bytes_per_ray": round(bytes_per_ray, 1),
             "records_per_ray": round(rec_per_ray, 2),
-            "note": "achieved counts the bytes the walk asks for (48 B per ray + 64 B per record fetched); with the batch ordered "
-                    "by origin cell the L2 serves most of them, so it can exceed the HBM peak; traffic is what crosses the fabric. "
-                    "Measured rates of the chip for this access pattern (scripts/microbench_fetch.hip, "
-                    "profiles/r01g_fetch_microbench.md): 56.5 G L2-miss lines/s, 217 G L2-hit records/s; a launch has "
-                    "0.89e9 misses and 1.75e9 hits (profiles/r01f_summary.md), 22.6 ms at those rates",
+            "note": "achieved = bytes that crossed the fabric per launch (traffic: 2 x FETCH_SIZE + WRITE_SIZE of separate "
+                    "rocprofv3 --pmc passes of this command, profiles/traffic.json) / kernel time measured here with HIP events; "
+                    "null when no counter record matches this workload.  requested_GBps = algorithmic bytes the walk asks for "
+                    "(48 B per ray + the records it fetches, counted by the counting build of the same kernel on a 2^20-ray "
+                    "prefix) / the same time: the L2 serves most of those, so it is not a fraction of the HBM peak",
         },
     }
 

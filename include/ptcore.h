@@ -175,8 +175,6 @@ PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes,
                           PtNode2* nodes2, PtTri* tris, float* root_box, uint32_t* max_stack,
                           char* err, size_t err_len);
 
-/* Replaces the constants block filled at PathTracer.cpp:731-750 (glm::lookAt, glm::perspective
- * with the y flip, glm::inverse) for the orbit camera of PathTracer.cpp:109-112. */
 /* The flattening pass with 48 B records.  leaf_ref[t] receives the reference node index of the leaf that holds
  * triangle t.  Returns 1 (and says so in err) if some box cannot be encoded; the caller then uses pt_flatten_bvh. */
 PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes,
@@ -184,6 +182,8 @@ PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes,
                                   PtNode2c* nodes2, PtTriC* tris, uint32_t* leaf_ref, float* root_box,
                                   uint32_t* max_stack, char* err, size_t err_len);
 
+/* Replaces the constants block filled at PathTracer.cpp:731-750 (glm::lookAt, glm::perspective
+ * with the y flip, glm::inverse) for the orbit camera of PathTracer.cpp:109-112. */
 PT_API void pt_fill_constants(PtShaderConstants* c, uint32_t width, uint32_t height,
                               const float focus_center[3], float orbit_height, float orbit_radius,
                               float orbit_angle, uint32_t num_lights, uint32_t num_triangles,
@@ -240,7 +240,13 @@ enum {
                                     0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
     PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 4): the ordering grid has 2^bits cells per axis */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
-                                    stack and pair of streams; results do not depend on it */
+                                    stack and pair of streams; results do not depend on it.  Three frames are six
+                                    streams, and HIP gives a process four hardware queues unless the environment
+                                    variable GPU_MAX_HW_QUEUES says otherwise when the runtime starts: with four, streams
+                                    share queues and wait on each other (about a tenth fewer frames per second at
+                                    1080p).  A host that renders with frames in flight should export
+                                    GPU_MAX_HW_QUEUES=8 (2 per frame in flight plus 2; never above 32) before its first
+                                    HIP call; the library cannot set it once the runtime is up */
 };
 PT_API int pt_set_option(PtContext* ctx, int option, int value);
 PT_API int pt_get_option(PtContext* ctx, int option, int* value);
@@ -320,8 +326,10 @@ PT_API int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const
 
 /* Traversal microbench (no reference dispatch site; it calls traceRay, intersections.glsl:57-115,
  * on caller-supplied rays).  d_rays / d_hits are DEVICE pointers; stats, if not NULL, is a host
- * array of 4 uint64 that receives {box tests, triangle tests, node records fetched, rays} (a
- * counting build of the same kernel runs instead of the plain one). */
+ * array of 4 uint64 that receives {box tests, triangle tests, node records fetched in 64 B units, ray walks} (a
+ * counting build of the same kernel runs instead of the plain one).  All four count every walk: under
+ * PT_OPT_TRAVERSAL = 3 a ray listed for the second, reference-order walk is walked twice and counts twice, so
+ * stats[3] - num_rays is the number of rays that took the second walk. */
 PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit,
                          PtHit* d_hits, uint64_t* stats);
 /* Same with HOST pointers: copies in, traces, copies out. */

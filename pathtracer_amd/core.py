@@ -46,7 +46,8 @@ class PtError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libptcore.so")
+    """The product library, or the experiment build PTCORE_LIB names (scripts/exp_variant.sh; never set by tests or bench)."""
+    return os.environ.get("PTCORE_LIB") or os.path.join(_HERE, "libptcore.so")
 
 
 _lib = None

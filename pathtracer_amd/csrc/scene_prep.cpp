@@ -65,18 +65,12 @@ const char* validate_tree(const PtBVHNode* nodes, uint32_t num_nodes, uint32_t n
     return nullptr;
 }
 
-}  // namespace
-
-extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
-                                     uint32_t num_triangles, PtNode2* nodes2, PtTri* tris, float* root_box, uint32_t* max_stack,
-                                     char* err, size_t err_len)
-try {
-    if (!nodes || !positions || !indices || !tris || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh: null argument"); return -1; }
+/* Shared by both flattening passes: rank of every reference node among the interior nodes (pre-order) or, for a leaf,
+ * its triangle index; returns 0 or an error code with a message. */
+int rank_nodes(const PtBVHNode* nodes, uint32_t num_nodes, uint32_t num_triangles, std::vector<uint32_t>& rank, char* err, size_t err_len)
+{
     if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
-    if (const char* why = validate_tree(nodes, num_nodes, num_triangles)) { set_err(err, err_len, (std::string("pt_flatten_bvh: ") + why).c_str()); return -3; }
-
-    /* interior rank of every reference node (pre-order is kept, so a left child is rank+1 when interior) */
-    std::vector<uint32_t> rank(num_nodes);
+    rank.resize(num_nodes);
     uint32_t ni = 0;
     for (uint32_t i = 0; i < num_nodes; i++) {
         if (nodes[i].right > 0) {
@@ -89,6 +83,33 @@ try {
         }
     }
     if (ni != num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: interior count is not T-1"); return -2; }
+    return 0;
+}
+
+uint32_t tree_depth(const PtBVHNode* nodes)
+{
+    /* depth of the deepest node = the most entries a depth-first walk can have pending */
+    uint32_t deepest = 0;
+    std::vector<uint32_t> st = { 0 }, dp = { 0 };
+    while (!st.empty()) {
+        uint32_t i = st.back(), d = dp.back(); st.pop_back(); dp.pop_back();
+        if (d > deepest) deepest = d;
+        if (nodes[i].right > 0) { st.push_back((uint32_t)nodes[i].right); dp.push_back(d + 1); st.push_back(i + 1); dp.push_back(d + 1); }
+    }
+    return deepest;
+}
+
+}  // namespace
+
+extern "C" PT_API int pt_flatten_bvh(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
+                                     uint32_t num_triangles, PtNode2* nodes2, PtTri* tris, float* root_box, uint32_t* max_stack,
+                                     char* err, size_t err_len)
+try {
+    if (!nodes || !positions || !indices || !tris || (num_triangles > 1 && !nodes2)) { set_err(err, err_len, "pt_flatten_bvh: null argument"); return -1; }
+    if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
+    if (const char* why = validate_tree(nodes, num_nodes, num_triangles)) { set_err(err, err_len, (std::string("pt_flatten_bvh: ") + why).c_str()); return -3; }
+    std::vector<uint32_t> rank;
+    if (int rc = rank_nodes(nodes, num_nodes, num_triangles, rank, err, err_len)) return rc;
 
     auto child_ref = [&](uint32_t i) { return nodes[i].right > 0 ? rank[i] : (PT_LEAF_BIT | rank[i]); };
 
@@ -139,53 +160,9 @@ try {
             if (nodes[i].right > 0) nodes2[rank[i]].flags = (uint32_t)thin[i + 1] | ((uint32_t)thin[nodes[i].right] << 1);
     }
 
-    if (max_stack) {
-        /* depth of the deepest node = the most entries a depth-first walk can have pending */
-        uint32_t deepest = 0;
-        std::vector<uint32_t> st = { 0 }, dp = { 0 };
-        while (!st.empty()) {
-            uint32_t i = st.back(), d = dp.back(); st.pop_back(); dp.pop_back();
-            if (d > deepest) deepest = d;
-            if (nodes[i].right > 0) { st.push_back((uint32_t)nodes[i].right); dp.push_back(d + 1); st.push_back(i + 1); dp.push_back(d + 1); }
-        }
-        *max_stack = deepest;
-    }
+    if (max_stack) *max_stack = tree_depth(nodes);
     return 0;
 } catch (...) { set_err(err, err_len, "pt_flatten_bvh: out of memory"); return -4; }
-
-/* Shared by both flattening passes: rank of every reference node among the interior nodes (pre-order) or, for a leaf,
- * its triangle index; returns 0 or an error code with a message. */
-static int rank_nodes(const PtBVHNode* nodes, uint32_t num_nodes, uint32_t num_triangles, std::vector<uint32_t>& rank, char* err, size_t err_len)
-{
-    if (num_nodes != 2 * num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: node count is not 2T-1"); return -2; }
-    rank.resize(num_nodes);
-    uint32_t ni = 0;
-    for (uint32_t i = 0; i < num_nodes; i++) {
-        if (nodes[i].right > 0) {
-            if ((uint32_t)nodes[i].right >= num_nodes || i + 1 >= num_nodes) { set_err(err, err_len, "pt_flatten_bvh: child index out of range"); return -3; }
-            rank[i] = ni++;
-        } else {
-            uint32_t off = (uint32_t)(-nodes[i].right);
-            if (off % 3 != 0 || off / 3 >= num_triangles) { set_err(err, err_len, "pt_flatten_bvh: leaf offset out of range"); return -3; }
-            rank[i] = off / 3;
-        }
-    }
-    if (ni != num_triangles - 1) { set_err(err, err_len, "pt_flatten_bvh: interior count is not T-1"); return -2; }
-    return 0;
-}
-
-static uint32_t tree_depth(const PtBVHNode* nodes)
-{
-    /* depth of the deepest node = the most entries a depth-first walk can have pending */
-    uint32_t deepest = 0;
-    std::vector<uint32_t> st = { 0 }, dp = { 0 };
-    while (!st.empty()) {
-        uint32_t i = st.back(), d = dp.back(); st.pop_back(); dp.pop_back();
-        if (d > deepest) deepest = d;
-        if (nodes[i].right > 0) { st.push_back((uint32_t)nodes[i].right); dp.push_back(d + 1); st.push_back(i + 1); dp.push_back(d + 1); }
-    }
-    return deepest;
-}
 
 extern "C" PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
                                              uint32_t num_triangles, PtNode2c* nodes2, PtTriC* tris, uint32_t* leaf_ref, float* root_box,

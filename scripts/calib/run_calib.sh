@@ -2,6 +2,7 @@
 # GPU box: FETCH_SIZE of three access patterns with a known byte count (4.29 GB each).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/calib; mkdir -p $OUT
+[ -x scripts/calib/calib_fetch ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o scripts/calib/calib_fetch scripts/calib/calib_fetch.hip || exit 1
 for P in 0 1 2; do
   timeout -k 10 60 scripts/calib/calib_fetch $P > $OUT/time_$P.txt 2>&1 || exit 1
   timeout -s KILL 60 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$P -o c -- scripts/calib/calib_fetch $P > $OUT/pmc_$P.txt 2>&1 || exit 1
