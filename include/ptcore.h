@@ -332,6 +332,16 @@ PT_API int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const
  * stats[3] - num_rays is the number of rays that took the second walk. */
 PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit,
                          PtHit* d_hits, uint64_t* stats);
+/* pt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same rays in, same hits out, byte for byte, but
+ * the call allocates and frees nothing: the ray-id counters, the ordering pass's bins, keys and order, the certified
+ * walk's list and the spill area of the traversal stacks all live in one static device array of 52 MiB that every GPU
+ * the library runs on holds from the first pt_ctx_create on it until the process ends.  Limits: at most 2^21
+ * (2 097 152) rays per call (-1 beyond that), and a tree whose depth beyond the 12 stack entries kept in LDS fits the
+ * array's 32 MiB spill area with at least one workgroup per CU (depth <= 76 on a 256-CU part; -1 otherwise; a deep
+ * tree runs with fewer workgroups than pt_trace_rays would use).  All calls on one GPU share that GPU's array, from
+ * whatever context: calls that overlap in time on one GPU race; calls on one context are ordered on its stream. */
+PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits);
 /* Same with HOST pointers: copies in, traces, copies out. */
 PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t num_rays, int any_hit,
                               PtHit* hits, uint64_t* stats);

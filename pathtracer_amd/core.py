@@ -110,6 +110,7 @@ def _load():
         "pt_tonemap": (i32, [vp, vp, vp]),
         "pt_write_ppm": (i32, [cp, u32, u32, vp]),
         "pt_trace_rays": (i32, [vp, vp, u64, i32, vp, vp]),
+        "pt_trace_rays_noalloc": (i32, [vp, vp, u64, i32, vp]),
         "pt_trace_rays_host": (i32, [vp, vp, u64, i32, vp, vp]),
         "pt_generate_rays": (i32, [vp, u64, u64, u64, vp]),
         "pt_device_alloc": (vp, [vp, sz]),
@@ -406,6 +407,10 @@ class PathTracer:
         st = np.zeros(4, dtype=np.uint64) if want_stats else None
         self._chk(self._L.pt_trace_rays(self._h, d_rays.ptr, n, int(any_hit), d_hits.ptr, _p(st)))
         return st
+
+    def trace_rays_device_noalloc(self, d_rays, n, d_hits, any_hit=False):
+        """pt_trace_rays_noalloc: the same batch through the static scratch array, nothing allocated."""
+        self._chk(self._L.pt_trace_rays_noalloc(self._h, d_rays.ptr, n, int(any_hit), d_hits.ptr))
 
     def trace_rays(self, rays, any_hit=False, want_stats=False):
         rays = np.ascontiguousarray(rays)

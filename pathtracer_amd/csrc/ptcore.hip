@@ -57,6 +57,48 @@ bool load_nccl(std::string& err)
 
 }  // namespace
 
+/* ---- scratch of pt_trace_rays_noalloc, the entry point that allocates nothing -------------------------------------
+ * Everything pt_trace_rays keeps in buffers of its own (allocated on first use, grown on demand) has a fixed place in
+ * one file-scope device array: the ray-id counter, the certified walk's two counters, the ordering pass's bin counts
+ * and cursors, its keys and the order it produces, the certified walk's list of rays to walk again, and the spill area
+ * of the per-lane traversal stacks.  Every GPU the library runs on holds its own copy of the array, at its own address,
+ * for the life of the process.  In host code the array's name is not a device address: the address is asked for once
+ * per device (pt_ctx_create, with that device current) and kept in g_scratchPtr; kernels, memsets and copies are given
+ * that pointer only. */
+enum : size_t {
+    NA_MAX_RAYS    = (size_t)1 << 21,                          /* rays per call */
+    NA_OFF_CTR     = 0,                                        /* u32[64]: [0] ray-id counter, [1] listed rays, [2] second walk's ray-id counter */
+    NA_OFF_BINS    = 256,                                      /* u32[2 * PT_SORT_BINS]: counts, cursors */
+    NA_OFF_ORDER   = NA_OFF_BINS + 2 * PT_SORT_BINS * 4,       /* u32[NA_MAX_RAYS] */
+    NA_OFF_KEYS    = NA_OFF_ORDER + NA_MAX_RAYS * 4,           /* u16[NA_MAX_RAYS] */
+    NA_OFF_FLAGS   = NA_OFF_KEYS + NA_MAX_RAYS * 2,            /* u32[NA_MAX_RAYS] */
+    NA_OFF_SPILL   = NA_OFF_FLAGS + NA_MAX_RAYS * 4,
+    NA_SPILL_BYTES = (size_t)32 << 20,                         /* uint2[entries beyond the LDS part][lanes of the launch] */
+    NA_TOTAL       = NA_OFF_SPILL + NA_SPILL_BYTES             /* 52.03 MiB */
+};
+static_assert(NA_OFF_BINS % 256 == 0 && NA_OFF_ORDER % 256 == 0 && NA_OFF_KEYS % 256 == 0 && NA_OFF_FLAGS % 256 == 0 && NA_OFF_SPILL % 256 == 0,
+              "every part of the scratch array starts on a 256 B boundary");
+static __device__ __align__(256) unsigned char scratch[NA_TOTAL];
+
+namespace {
+enum { PT_MAX_DEVICES = 64 };
+unsigned char* g_scratchPtr[PT_MAX_DEVICES] = { nullptr };     /* device address of `scratch` on each device, once resolved */
+std::mutex g_scratchMutex;
+
+/* Device address of this device's copy of the scratch array; the device must be current.  nullptr + message on failure. */
+unsigned char* resolve_scratch(int device, std::string& err)
+{
+    if (device < 0 || device >= PT_MAX_DEVICES) { err = "device id beyond the scratch table"; return nullptr; }
+    std::lock_guard<std::mutex> lk(g_scratchMutex);
+    if (g_scratchPtr[device]) return g_scratchPtr[device];
+    unsigned char* ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) { err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return nullptr; }
+    g_scratchPtr[device] = ptr;
+    return ptr;
+}
+}  // namespace
+
 enum { PT_MAX_PIPES = 8 };
 
 /* Everything one frame in flight owns: its ray stack, job lists, hit records, shadow queues, counters, and the two
@@ -113,6 +155,7 @@ struct PtContext {
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
+    unsigned char* scratchPtr = nullptr;    /* this device's copy of the scratch array (pt_trace_rays_noalloc) */
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -190,15 +233,29 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     a.stats = c->dStats;
 }
 
+/* Where a batch's scratch lives: buffers the context owns (pt_trace_rays) or parts of the static scratch array
+ * (pt_trace_rays_noalloc, which also fixes the spill area and with it the number of workgroups). */
+struct BatchScratch {
+    uint32_t* fetch = nullptr; uint32_t* sortOrder = nullptr; uint16_t* sortKeys = nullptr; uint32_t* sortBins = nullptr;
+    uint32_t* flagList = nullptr; uint32_t* flagCtr = nullptr;
+    uint2* spill = nullptr; uint32_t spillEntries = 0; int maxBlocks = 0;     /* maxBlocks != 0: spill and grid are fixed, nothing is allocated */
+};
+
 /* area: which spill area the launch may use (2*pipe for the pipe's first stream, 2*pipe+1 for its second) */
 template <int MODE, bool ANYHIT>
-int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, int area)
+int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, int area, const BatchScratch* fixed = nullptr)
 {
-    if (int rc = ensure_overflow(ctx)) return rc;
-    a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
-    a.overflowEntries = ctx->overflowEntries;
     const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
-    dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
+    int blocks = ctx->numCUs * blocks_per_cu(ctx, shape);
+    if (fixed && fixed->maxBlocks) {
+        a.overflow = fixed->spill; a.overflowEntries = fixed->spillEntries;
+        if (blocks > fixed->maxBlocks) blocks = fixed->maxBlocks;
+    } else {
+        if (int rc = ensure_overflow(ctx)) return rc;
+        a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
+        a.overflowEntries = ctx->overflowEntries;
+    }
+    dim3 grid(blocks), block(PT_BLOCK);
     a.refillMin = (uint32_t)refill_min(ctx, shape);
     /* 3 (certified walk): closest-hit passes launch k_trace_cert themselves (launch_cert) and come here for the second
        walk of the rays it listed, in reference order; any-hit passes get the near-first walk, whose verdict no order
@@ -234,21 +291,27 @@ int enter(PtContext* ctx) { HIPCHK(hipSetDevice(ctx->device)); return 0; }
 /* The certified walk over the batch or job list `a` describes, then the reference-order walk over the rays it listed.
  * flag: room for one index per ray; ctr: two zeroed words (count of listed rays, the second walk's fetch counter). */
 template <int MODE>
-int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, int area, uint32_t* flag, uint32_t* ctr)
+int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, int area, uint32_t* flag, uint32_t* ctr, const BatchScratch* fixed = nullptr)
 {
-    if (int rc = ensure_overflow(ctx)) return rc;
-    a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
-    a.overflowEntries = ctx->overflowEntries;
-    a.flagList = flag; a.flagCount = ctr;
     const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
+    int blocks = ctx->numCUs * blocks_per_cu(ctx, shape);
+    if (fixed && fixed->maxBlocks) {
+        a.overflow = fixed->spill; a.overflowEntries = fixed->spillEntries;
+        if (blocks > fixed->maxBlocks) blocks = fixed->maxBlocks;
+    } else {
+        if (int rc = ensure_overflow(ctx)) return rc;
+        a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
+        a.overflowEntries = ctx->overflowEntries;
+    }
+    a.flagList = flag; a.flagCount = ctr;
     a.refillMin = (uint32_t)refill_min(ctx, shape);
-    dim3 grid(ctx->numCUs * blocks_per_cu(ctx, shape)), block(PT_BLOCK);
+    dim3 grid(blocks), block(PT_BLOCK);
     if (count) hipLaunchKernelGGL((k_trace_cert<MODE, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_trace_cert<MODE, false>), grid, block, 0, stream, a);
     HIPCHK(hipGetLastError());
     TraceArgs b = a;
     b.order = flag; b.countPtr = ctr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
-    return launch_trace<MODE, false>(ctx, b, count, stream, area);        /* traversal 3 maps to the reference-order walk there */
+    return launch_trace<MODE, false>(ctx, b, count, stream, area, fixed);        /* traversal 3 maps to the reference-order walk there */
 }
 
 int check_scene(PtContext* ctx) { return ctx->T ? 0 : ctx->fail(-2, "no scene uploaded (call pt_scene_upload first)"); }
@@ -359,6 +422,9 @@ PT_API int pt_ctx_create(int device_id, PtContext** out)
         return -10;
     }
     memset(&ctx->consts, 0, sizeof(ctx->consts));
+    /* this device's copy of the static scratch array: its address is asked for here, with the device current */
+    ctx->scratchPtr = resolve_scratch(device_id, g_createError);
+    if (!ctx->scratchPtr) { pt_ctx_destroy(ctx); return -10; }
     *out = ctx;
     return 0;
 }
@@ -852,64 +918,69 @@ PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8)
     return 0;
 }
 
-PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits, uint64_t* stats)
+/* One batch through the ordering pass and the traversal kernels.  `sc` names the scratch: the context's own buffers
+ * (grown here when they are too small) or, with sc.maxBlocks set, fixed parts of the static scratch array, in which
+ * case nothing is allocated on the way. */
+static int trace_batch(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits, uint64_t* stats, BatchScratch& sc)
 {
-    if (!ctx) return -1;
-    if (int rc = enter(ctx)) return rc;
-    if (int rc = check_scene(ctx)) return rc;
-    if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays: null buffer");
-    /* the id counter is 32 bits wide and every wavefront may overshoot the count by one chunk */
-    if (num_rays > 0xFE000000ull) return ctx->fail(-1, "pt_trace_rays: at most 2^32-2^25 rays per call");
-    if (num_rays == 0) return 0;
-    HIPCHK(hipMemsetAsync(ctx->dFetch, 0, 4, ctx->stream));
-    if (stats) HIPCHK(hipMemsetAsync(ctx->dStats, 0, 32, ctx->stream));
-    TraceArgs a; fill_trace_args(ctx, a);
-    a.rays = d_rays; a.hits = d_hits; a.count = num_rays; a.countPtr = nullptr; a.fetchCounter = ctx->dFetch;
-    /* large batches are first ordered by the cell of the scene box their origin lies in (sort_kernels.h) */
+    const bool fixed = sc.maxBlocks != 0;
     const bool sort = ctx->optTraversal != 0 &&        /* the reference-layout kernel takes its rays in batch order */
                       (ctx->optSortRays == 1 || (ctx->optSortRays == 2 && num_rays >= (1u << 20)));
+    const bool certified = ctx->optTraversal == 3 && !any_hit && !ctx->compact && ctx->boxesNest;
+    if (!fixed) {
+        sc.fetch = ctx->dFetch;
+        if (sort) {
+            if (ctx->sortCapacity < num_rays) {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); ctx->sortCapacity = 0;
+                HIPCHK(hipMalloc((void**)&ctx->dSortOrder, num_rays * 4));
+                HIPCHK(hipMalloc((void**)&ctx->dSortKeys, num_rays * 2));
+                ctx->sortCapacity = num_rays;
+            }
+            if (!ctx->dSortBins) {
+                HIPCHK(hipMalloc((void**)&ctx->dSortBins, 2 * PT_SORT_BINS * 4));
+                HIPCHK(hipMemsetAsync(ctx->dSortBins, 0, 2 * PT_SORT_BINS * 4, ctx->stream));
+            }
+            sc.sortOrder = ctx->dSortOrder; sc.sortKeys = ctx->dSortKeys; sc.sortBins = ctx->dSortBins;
+        }
+        if (certified) {
+            if (ctx->flagCapacity < num_rays) {
+                HIPCHK(hipStreamSynchronize(ctx->stream));
+                dfree(ctx->dFlagList); ctx->flagCapacity = 0;
+                HIPCHK(hipMalloc((void**)&ctx->dFlagList, num_rays * 4));
+                ctx->flagCapacity = num_rays;
+            }
+            if (!ctx->dFlagCtr) HIPCHK(hipMalloc((void**)&ctx->dFlagCtr, 2 * 4));
+            sc.flagList = ctx->dFlagList; sc.flagCtr = ctx->dFlagCtr;
+        }
+    }
+    HIPCHK(hipMemsetAsync(sc.fetch, 0, 4, ctx->stream));
+    if (certified) HIPCHK(hipMemsetAsync(sc.flagCtr, 0, 2 * 4, ctx->stream));
+    if (stats) HIPCHK(hipMemsetAsync(ctx->dStats, 0, 32, ctx->stream));
+    TraceArgs a; fill_trace_args(ctx, a);
+    a.rays = d_rays; a.hits = d_hits; a.count = num_rays; a.countPtr = nullptr; a.fetchCounter = sc.fetch;
+    /* large batches are first ordered by the cell of the scene box their origin lies in (sort_kernels.h) */
     if (sort) {
-        if (ctx->sortCapacity < num_rays) {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); ctx->sortCapacity = 0;
-            HIPCHK(hipMalloc((void**)&ctx->dSortOrder, num_rays * 4));
-            HIPCHK(hipMalloc((void**)&ctx->dSortKeys, num_rays * 2));
-            ctx->sortCapacity = num_rays;
-        }
-        if (!ctx->dSortBins) {
-            HIPCHK(hipMalloc((void**)&ctx->dSortBins, 2 * PT_SORT_BINS * 4));
-            HIPCHK(hipMemsetAsync(ctx->dSortBins, 0, 2 * PT_SORT_BINS * 4, ctx->stream));
-        }
         const float* b = ctx->rootBox;
         const float cells = (float)(1 << ctx->optSortBits);
         const int nbins = 1 << (3 * ctx->optSortBits);
         auto scale = [cells](float lo, float hi) { float d = hi - lo; return d > 0.0f ? cells / d : 0.0f; };
         const uint32_t tiles = (uint32_t)((num_rays + PT_SORT_TILE - 1) / PT_SORT_TILE);
-        hipLaunchKernelGGL(k_bin_count, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, d_rays, num_rays, ctx->dSortKeys, ctx->dSortBins, nbins,
+        hipLaunchKernelGGL(k_bin_count, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, d_rays, num_rays, sc.sortKeys, sc.sortBins, nbins,
                            b[0], b[1], b[2], scale(b[0], b[3]), scale(b[1], b[4]), scale(b[2], b[5]), cells - 1.0f);
-        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(PT_SORT_BLOCK), 0, ctx->stream, ctx->dSortBins, ctx->dSortBins + PT_SORT_BINS);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, num_rays, ctx->dSortKeys,
-                           ctx->dSortBins + PT_SORT_BINS, nbins, ctx->dSortOrder);
+        hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(PT_SORT_BLOCK), 0, ctx->stream, sc.sortBins, sc.sortBins + PT_SORT_BINS);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(tiles), dim3(PT_SORT_BLOCK), 0, ctx->stream, num_rays, sc.sortKeys,
+                           sc.sortBins + PT_SORT_BINS, nbins, sc.sortOrder);
         HIPCHK(hipGetLastError());
-        a.order = ctx->dSortOrder;
-    }
-    const bool certified = ctx->optTraversal == 3 && !any_hit && !ctx->compact && ctx->boxesNest;
-    if (certified) {
-        if (ctx->flagCapacity < num_rays) {
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            dfree(ctx->dFlagList); ctx->flagCapacity = 0;
-            HIPCHK(hipMalloc((void**)&ctx->dFlagList, num_rays * 4));
-            ctx->flagCapacity = num_rays;
-        }
-        if (!ctx->dFlagCtr) HIPCHK(hipMalloc((void**)&ctx->dFlagCtr, 2 * 4));
-        HIPCHK(hipMemsetAsync(ctx->dFlagCtr, 0, 2 * 4, ctx->stream));
+        a.order = sc.sortOrder;
     }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = 0;
+    const BatchScratch* fx = fixed ? &sc : nullptr;
     if (certified) {
-        rc = launch_cert<MODE_RAYS>(ctx, a, stats != nullptr, ctx->stream, 0, ctx->dFlagList, ctx->dFlagCtr);
+        rc = launch_cert<MODE_RAYS>(ctx, a, stats != nullptr, ctx->stream, 0, sc.flagList, sc.flagCtr, fx);
     } else {
-        rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0);
+        rc = any_hit ? launch_trace<MODE_RAYS, true>(ctx, a, stats != nullptr, ctx->stream, 0, fx) : launch_trace<MODE_RAYS, false>(ctx, a, stats != nullptr, ctx->stream, 0, fx);
     }
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -919,6 +990,54 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     return 0;
+}
+
+PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits, uint64_t* stats)
+{
+    if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
+    if (int rc = check_scene(ctx)) return rc;
+    if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays: null buffer");
+    /* the id counter is 32 bits wide and every wavefront may overshoot the count by one chunk */
+    if (num_rays > 0xFE000000ull) return ctx->fail(-1, "pt_trace_rays: at most 2^32-2^25 rays per call");
+    if (num_rays == 0) return 0;
+    BatchScratch sc;
+    return trace_batch(ctx, d_rays, num_rays, any_hit, d_hits, stats, sc);
+}
+
+PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits)
+{
+    if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
+    if (int rc = check_scene(ctx)) return rc;
+    if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays_noalloc: null buffer");
+    if (num_rays > NA_MAX_RAYS) return ctx->fail(-1, "pt_trace_rays_noalloc: at most 2^21 (2 097 152) rays per call; larger batches need pt_trace_rays");
+    if (num_rays == 0) return 0;
+    unsigned char* base = ctx->scratchPtr;
+    if (!base) return ctx->fail(-2, "pt_trace_rays_noalloc: the scratch array's device address was not resolved at pt_ctx_create");
+    BatchScratch sc;
+    /* the spill area holds (tree depth - LDS part) entries per lane of the launch: the launch takes as many workgroups
+       as fit, up to its usual number; a tree too deep for even one workgroup per CU is refused */
+    sc.spillEntries = ctx->maxStack > PT_STACK_LDS ? ctx->maxStack - PT_STACK_LDS : 0;
+    sc.maxBlocks = ctx->numCUs * 8;
+    if (sc.spillEntries) {
+        const size_t perBlock = (size_t)sc.spillEntries * PT_BLOCK * sizeof(uint2);
+        const size_t fit = NA_SPILL_BYTES / perBlock;
+        if (fit < (size_t)ctx->numCUs)
+            return ctx->fail(-1, "pt_trace_rays_noalloc: the tree is too deep for the 32 MiB spill area of the static scratch (use pt_trace_rays)");
+        if (fit < (size_t)sc.maxBlocks) sc.maxBlocks = (int)fit;
+    }
+    sc.fetch = (uint32_t*)(base + NA_OFF_CTR);
+    sc.flagCtr = sc.fetch + 1;
+    sc.sortBins = (uint32_t*)(base + NA_OFF_BINS);
+    sc.sortOrder = (uint32_t*)(base + NA_OFF_ORDER);
+    sc.sortKeys = (uint16_t*)(base + NA_OFF_KEYS);
+    sc.flagList = (uint32_t*)(base + NA_OFF_FLAGS);
+    sc.spill = (uint2*)(base + NA_OFF_SPILL);
+    /* the array keeps what the last call on this GPU left: counters and bin counts start from zero (the rest is
+       written before it is read) */
+    HIPCHK(hipMemsetAsync(base + NA_OFF_CTR, 0, NA_OFF_ORDER - NA_OFF_CTR, ctx->stream));
+    return trace_batch(ctx, d_rays, num_rays, any_hit, d_hits, nullptr, sc);
 }
 
 PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t n, int any_hit, PtHit* hits, uint64_t* stats)
