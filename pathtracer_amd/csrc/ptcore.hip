@@ -361,12 +361,15 @@ int ensure_pipe(PtContext* ctx, int k)
     HIPCHK(hipMalloc((void**)&p.dShadow[1], px * sizeof(PtShadowRay)));
     HIPCHK(hipMalloc((void**)&p.dCtr, (size_t)ctr_words(ctx->slots) * 4));
     HIPCHK(hipMalloc((void**)&p.dRayCounts, (size_t)2 * ctx->slots * 8));
-    /* the reference leaves these undefined; zero makes the first frame deterministic */
-    HIPCHK(hipMemset(p.dStack, 0, px * ctx->slots * sizeof(PtRayStackSlot)));
-    HIPCHK(hipMemset(p.dJobs[0], 0xFF, px * 4));
-    HIPCHK(hipMemset(p.dJobs[1], 0xFF, px * 4));
-    HIPCHK(hipMemset(p.dCtr, 0, (size_t)ctr_words(ctx->slots) * 4));
-    HIPCHK(hipMemset(p.dRayCounts, 0, (size_t)2 * ctx->slots * 8));
+    /* the reference leaves these undefined; zero makes the first frame deterministic.  The fills are queued on the
+       pipe's own stream, ahead of everything that will ever touch these buffers: a fill of device memory on the null
+       stream returns before it has run and is not ordered against the non-blocking streams the frames run on (a
+       3 GB ray stack was still being zeroed while the first frame wrote to it) */
+    HIPCHK(hipMemsetAsync(p.dStack, 0, px * ctx->slots * sizeof(PtRayStackSlot), p.stream));
+    HIPCHK(hipMemsetAsync(p.dJobs[0], 0xFF, px * 4, p.stream));
+    HIPCHK(hipMemsetAsync(p.dJobs[1], 0xFF, px * 4, p.stream));
+    HIPCHK(hipMemsetAsync(p.dCtr, 0, (size_t)ctr_words(ctx->slots) * 4, p.stream));
+    HIPCHK(hipMemsetAsync(p.dRayCounts, 0, (size_t)2 * ctx->slots * 8, p.stream));
     p.ready = true; p.curJobs = 0;
     return 0;
 }
@@ -609,8 +612,8 @@ PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
     ctx->W = W; ctx->H = H; ctx->slots = max_slots;
     HIPCHK(hipMalloc((void**)&ctx->dAccum, px * 16));
     HIPCHK(hipMalloc((void**)&ctx->dCurrent, px * 8));
-    HIPCHK(hipMemset(ctx->dAccum, 0, px * 16));
-    HIPCHK(hipMemset(ctx->dCurrent, 0, px * 8));
+    HIPCHK(hipMemsetAsync(ctx->dAccum, 0, px * 16, ctx->stream));        /* on the context's stream: see ensure_pipe */
+    HIPCHK(hipMemsetAsync(ctx->dCurrent, 0, px * 8, ctx->stream));
     ctx->accumEmpty = true;
     if (int rc = ensure_pipe(ctx, 0)) { free_frame(ctx); return rc; }      /* further pipes come with the first pt_render_samples */
     return 0;

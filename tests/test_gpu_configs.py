@@ -56,9 +56,9 @@ def _prepare(ctx, model, W, H, NR, trav, reseed=0, in_flight=3):
     ctx.set_constants(_consts(model, W, H, NR, 1, CAM))
 
 
-def _check_counts(rc, NR, W, H):
+def _check_counts(rc, NR, W, H, frames=1):
     closest, shadow = rc[0:2 * NR:2].astype(np.int64), rc[1:2 * NR:2].astype(np.int64)
-    assert closest[0] == W * H
+    assert closest[0] == frames * W * H
     assert (shadow <= closest).all()                      # one shadow ray per hit (trace.comp:123)
     assert (closest[1:] <= shadow[:-1]).all()             # a path goes on only from a hit (trace.comp:212-227)
     assert closest[-1] > 0                                # some paths do reach the last bounce
@@ -102,8 +102,7 @@ def test_sponza_1080p_8_bounces_properties(ctx, sponza):
     for rep in range(2):
         ctx.clear_accumulation()
         rc = ctx.render_samples(1, NF, want_ray_counts=True)
-        _check_counts(rc, NR, W, H)
-        assert rc[0] == NF * W * H
+        _check_counts(rc, NR, W, H, NF)
         acc = ctx.readback_accumulation()
         _check_image(acc, NF)
         images.append(acc)
@@ -126,8 +125,7 @@ def test_san_miguel_4k_8_bounces_properties(ctx, san_miguel):
     W, H, NR, NF = 3840, 2160, 8, 2
     _prepare(ctx, san_miguel, W, H, NR, core.TRAVERSAL_FLAT_ORDERED, reseed=1, in_flight=2)
     rc = ctx.render_samples(1, NF, want_ray_counts=True)
-    _check_counts(rc, NR, W, H)
-    assert rc[0] == NF * W * H
+    _check_counts(rc, NR, W, H, NF)
     acc = ctx.readback_accumulation()
     _check_image(acc, NF)
     first = acc.copy()
