@@ -146,6 +146,29 @@ typedef struct PtTri {
 } PtTri;
 #define PT_LEAF_BIT 0x80000000u
 
+/* Two-level treelet record, 128 B = one HBM line (PT_OPT_RECORD_LAYOUT = 2): the boxes of the two children L, R of
+ * one interior node X of the reference tree AND of their children LL, LR, RL, RR, so that a walk pays one dependent
+ * fetch per two levels of the tree and uses every byte of the line it fetched.  Every intermediate box is kept and
+ * tested exactly as the reference tests it (intersections.glsl:1-30 on the digest c, f16(a-c), f16(b-c), the last
+ * rebuilt from the 5-bit differences as in PtNode2c): nothing is re-quantised and no test is dropped.
+ * Records and leaves (PtTri) share one buffer addressed in 64 B units, laid out depth first: X's record at unit u
+ * (u even), then the subtrees of its up to four targets T0..T3 in that order, where
+ *   L interior: T0 = LL, T1 = LR;  L a leaf: T0 = L's PtTri, no T1;   R interior: T2 = RL, T3 = RR;  R a leaf: T2 = R's PtTri.
+ * An interior target is the treelet record of that node, a leaf target its PtTri.  T0 always starts at u + 2; the
+ * starts of T1, T2, T3 are stored relative to u. */
+typedef struct PtTreeletPair {
+    float    c[3][2];            /* box centres x, y, z as (first, second) pairs */
+    uint16_t hA[3][2];           /* f16(a-c).xyz as pairs */
+    uint32_t delta;              /* as PtNode2c.delta (bits 0..14 first box, 16..30 second box); bits 15 and 31 are flags:
+                                    pair[0]: L is a leaf / R is a leaf;  pair[1]: LL / LR is a leaf;  pair[2]: RL / RR is a leaf */
+} PtTreeletPair;
+typedef struct PtTreelet {
+    PtTreeletPair pair[3];       /* (L, R), (LL, LR), (RL, RR); a pair whose parent is a leaf is zero */
+    uint32_t link[2];            /* 64 bits: start of T1, T2, T3 minus u in bits 0..20, 21..41, 42..62, in 64 B units,
+                                    or in steps of 32 units if bit 63 is set (subtrees beyond 2^21 units) */
+} PtTreelet;
+#define PT_PAIR_BIT 0x40000000u  /* traversal-stack flag, see k_trace_tree */
+
 /* ------------------------------------------------------------------------------------------
  * Host-side scene preparation (no GPU needed).
  * ---------------------------------------------------------------------------------------- */
@@ -181,6 +204,14 @@ PT_API int pt_flatten_bvh_compact(const PtBVHNode* nodes, uint32_t num_nodes,
                                   const float* positions, const uint32_t* indices, uint32_t num_triangles,
                                   PtNode2c* nodes2, PtTriC* tris, uint32_t* leaf_ref, float* root_box,
                                   uint32_t* max_stack, char* err, size_t err_len);
+
+/* The flattening pass with treelet records.  units: room for capacity_units x 64 B, or NULL to only compute
+ * *num_units (call twice).  max_stack receives the most entries a walk over this layout can have pending.
+ * Returns 1 (and says so in err) if some box cannot be encoded; the caller then uses pt_flatten_bvh. */
+PT_API int pt_flatten_bvh_treelets(const PtBVHNode* nodes, uint32_t num_nodes,
+                                   const float* positions, const uint32_t* indices, uint32_t num_triangles,
+                                   void* units, uint64_t capacity_units, uint64_t* num_units, float* root_box,
+                                   uint32_t* max_stack, char* err, size_t err_len);
 
 /* Replaces the constants block filled at PathTracer.cpp:731-750 (glm::lookAt, glm::perspective
  * with the y flip, glm::inverse) for the orbit camera of PathTracer.cpp:109-112. */
@@ -231,10 +262,13 @@ enum {
                                     and 12 for the same three uses */
     PT_OPT_CLAIM_CHUNK    = 6,   /* ray ids a wavefront takes from the global counter at a time: 0 = chosen from the
                                     ray count (64..128), else 64..1024 in steps of 64 */
-    PT_OPT_RECORD_LAYOUT  = 8,   /* read by pt_scene_upload: 0 (default) = 64 B records; 1 = 48 B records when every box
-                                    can be encoded (pt_flatten_bvh_compact), else 64 B.  Results do not depend on it;
-                                    48 B records save a quarter of the record memory and measure about 5 % slower
-                                    (one record in four then lies across two 128 B lines) */
+    PT_OPT_RECORD_LAYOUT  = 8,   /* read by pt_scene_upload: 0 = 64 B records; 1 = 48 B records when every box
+                                    can be encoded (pt_flatten_bvh_compact), else 64 B; 2 = 128 B two-level treelet
+                                    records (PtTreelet) beside the 64 B records when every box can be encoded, else
+                                    64 B only: traversals 1 and 2 and every any-hit walk then run on the treelets, the
+                                    certified walk's first pass and traversal 0 on what they always use.  Results do
+                                    not depend on the layout, bit for bit.  48 B records save a quarter of the record
+                                    memory and measure about 5 % slower (one record in four lies across two lines) */
     PT_OPT_SORT_RAYS      = 9,   /* pt_trace_rays orders a batch by the cell of the scene box each origin lies in before
                                     tracing it (results are stored under the rays' own indices and do not change):
                                     0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
@@ -404,5 +438,6 @@ PT_SA(sizeof(PtBVHNode) == 32 && offsetof(PtBVHNode, next) == 12 && offsetof(PtB
 PT_SA(sizeof(PtRay) == 32 && sizeof(PtHit) == 16, "microbench ray 32 B, hit 16 B");
 PT_SA(sizeof(PtNode2) == 64 && sizeof(PtTri) == 64, "flattened records are 64 B");
 PT_SA(sizeof(PtNode2c) == 48 && sizeof(PtTriC) == 48, "compact flattened records are 48 B");
+PT_SA(sizeof(PtTreeletPair) == 40 && sizeof(PtTreelet) == 128 && offsetof(PtTreelet, link) == 120, "treelet record is 128 B");
 
 #endif /* PTCORE_H */

@@ -30,14 +30,17 @@ CONST_DT = np.dtype([("viewMtx", "<f4", 16), ("projMtx", "<f4", 16), ("viewInvMt
 NODE2C_DT = np.dtype([("c", "<f4", (3, 2)), ("hA", "<u2", (3, 2)), ("left", "<u4"), ("right", "<u4"), ("delta", "<u4")])
 TRIC_DT = np.dtype([("p1", "<f4", 3), ("i1", "<i4"), ("e1", "<f4", 3), ("i2", "<i4"), ("e2", "<f4", 3), ("i3", "<i4")])
 assert (NODE_DT.itemsize, NODE2_DT.itemsize, TRI_DT.itemsize, RAY_DT.itemsize, HIT_DT.itemsize) == (32, 64, 64, 32, 16)
-assert (NODE2C_DT.itemsize, TRIC_DT.itemsize) == (48, 48)
+PAIR_DT = np.dtype([("c", "<f4", (3, 2)), ("hA", "<u2", (3, 2)), ("delta", "<u4")])
+TREELET_DT = np.dtype([("pair", PAIR_DT, 3), ("link", "<u4", 2)])
+assert (NODE2C_DT.itemsize, TRIC_DT.itemsize) == (48, 48) and (PAIR_DT.itemsize, TREELET_DT.itemsize) == (40, 128)
 assert (LIGHT_DT.itemsize, AUX_DT.itemsize, SLOT_DT.itemsize, CONST_DT.itemsize) == (32, 16, 48, 320)
 
 OPT_TRAVERSAL, OPT_STALE_SLOTS, OPT_RESEED, OPT_PERSIST_BLOCKS, OPT_REFILL_MIN, OPT_CLAIM_CHUNK = 1, 2, 3, 4, 5, 6
 OPT_FRAMES_IN_FLIGHT = 7
 OPT_SORT_RAYS = 9               # 0 = never, 1 = always, 2 = batches of 2^20 rays or more (default)
 OPT_SORT_BITS = 10
-OPT_RECORD_LAYOUT = 8           # 0 = 64 B records (default), 1 = 48 B records when every box can be encoded
+OPT_RECORD_LAYOUT = 8           # 0 = 64 B records, 1 = 48 B records, 2 = 128 B treelet records beside the 64 B ones
+LAYOUT_RECORDS64, LAYOUT_RECORDS48, LAYOUT_TREELETS = 0, 1, 2
 TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED, TRAVERSAL_CERTIFIED = 0, 1, 2, 3
 
 
@@ -80,6 +83,7 @@ def _load():
         "pt_build_bvh": (i32, [vp, u32, vp, u32, vp, pu32, i32, cp, sz]),
         "pt_flatten_bvh": (i32, [vp, u32, vp, vp, u32, vp, vp, vp, pu32, cp, sz]),
         "pt_flatten_bvh_compact": (i32, [vp, u32, vp, vp, u32, vp, vp, vp, vp, pu32, cp, sz]),
+        "pt_flatten_bvh_treelets": (i32, [vp, u32, vp, vp, u32, vp, u64, C.POINTER(u64), vp, pu32, cp, sz]),
         "pt_fill_constants": (None, [vp, u32, u32, vp, C.c_float, C.c_float, C.c_float, u32, u32, u32, u32, u32, vp]),
         "pt_ctx_create": (i32, [i32, C.POINTER(vp)]),
         "pt_ctx_destroy": (None, [vp]),
@@ -207,6 +211,30 @@ def flatten_bvh_compact(nodes, positions, indices):
     if rc != 0:
         raise PtError(err.value.decode())
     return n2[:max(T - 1, 0)], tr, lr, rb, ms.value
+
+
+def flatten_bvh_treelets(nodes, positions, indices):
+    """The flattening pass with 128 B treelet records.  Returns (units [n, 16] u32: the depth-first stream of 64 B
+    units holding TREELET_DT records (two units each) and TRI_DT leaves, root_box [6], max_stack), or None if some
+    box does not fit the encoding."""
+    L = _load()
+    nodes = np.ascontiguousarray(nodes)
+    pos = np.ascontiguousarray(positions, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    T = idx.shape[0]
+    rb = np.zeros(6, dtype=np.float32)
+    ms, nu = C.c_uint32(0), C.c_uint64(0)
+    err = C.create_string_buffer(256)
+    rc = L.pt_flatten_bvh_treelets(_p(nodes), nodes.shape[0], _p(pos), _p(idx), T, None, 0, C.byref(nu), _p(rb), C.byref(ms), err, 256)
+    if rc < 0:
+        raise PtError(err.value.decode())
+    units = np.zeros((nu.value, 16), dtype=np.uint32)
+    rc = L.pt_flatten_bvh_treelets(_p(nodes), nodes.shape[0], _p(pos), _p(idx), T, _p(units), nu.value, C.byref(nu), _p(rb), C.byref(ms), err, 256)
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise PtError(err.value.decode())
+    return units, rb, ms.value
 
 
 def fill_constants(width, height, num_rays, num_triangles, num_bvh_nodes, frame_index=1, focus_center=(0.0, 0.0, 0.0),

@@ -131,6 +131,7 @@ struct PtContext {
     PtLight* dLights = nullptr; uint16_t* dBlueNoise = nullptr;
     uint4* dRecords = nullptr; uint2* dOverflow = nullptr; uint32_t leafBase = 0, recordBytes = 0;
     bool compact = false; uint32_t* dLeafRef = nullptr; uint32_t lastLeaf = 0;      /* 48 B records */
+    uint4* dTreelets = nullptr; uint32_t treeletBytes = 0, treeletMaxStack = 0;      /* 128 B treelet records + leaves, beside the 64 B records */
     uint32_t V = 0, T = 0, N = 0, L = 0, maxStack = 0, overflowEntries = 0;
     uint64_t overflowLanes = 0; int overflowAreas = 0;
     float rootBox[6] = {0}; float rootC[3] = {0}; uint16_t rootH[6] = {0};
@@ -173,7 +174,8 @@ template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; }
 void free_scene(PtContext* c)
 {
     dfree(c->dPositions); dfree(c->dAux); dfree(c->dIndices); dfree(c->dNodes); dfree(c->dLights); dfree(c->dBlueNoise);
-    dfree(c->dRecords); dfree(c->dOverflow); dfree(c->dLeafRef);
+    dfree(c->dRecords); dfree(c->dOverflow); dfree(c->dLeafRef); dfree(c->dTreelets);
+    c->treeletBytes = 0; c->treeletMaxStack = 0;
     c->V = c->T = c->N = c->L = 0;
 }
 void free_pipe_buffers(FramePipe& p)
@@ -203,9 +205,17 @@ int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 6 || c->
 
 /* Spill areas of the LDS stacks: one per traversal kernel that can be running at a time, that is two per pipe
  * (closest-hit pass and shadow pass side by side). */
+/* Entries a lane's stack can need beyond its LDS part: the tree's depth for the two-box walks; a level of the treelet
+ * walk can leave three entries behind where two levels of a two-box walk leave two. */
+uint32_t spill_entries(const PtContext* c)
+{
+    const uint32_t deepest = c->maxStack > c->treeletMaxStack ? c->maxStack : c->treeletMaxStack;
+    return deepest > PT_STACK_LDS ? deepest - PT_STACK_LDS : 0;
+}
+
 int ensure_overflow(PtContext* ctx)
 {
-    uint32_t need = ctx->maxStack > PT_STACK_LDS ? ctx->maxStack - PT_STACK_LDS : 0;
+    uint32_t need = spill_entries(ctx);
     uint64_t lanes = (uint64_t)grid_blocks(ctx) * PT_BLOCK;
     int areas = 2;
     for (int k = 1; k < PT_MAX_PIPES; k++) if (ctx->pipe[k].ready) areas = 2 * (k + 1);
@@ -223,6 +233,7 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     a.nodes = c->dNodes; a.numNodes = c->N; a.indices = c->dIndices; a.positions = c->dPositions;
     a.records = c->dRecords; a.recordBytes = c->recordBytes; a.leafBase = c->leafBase; a.tris = c->dRecords + c->leafBase / 16;
     a.leafRef = c->dLeafRef; a.lastLeaf = c->lastLeaf;
+    a.treelets = c->dTreelets; a.treeletBytes = c->treeletBytes;
     for (int k = 0; k < 3; k++) a.rootC[k] = c->rootC[k];
     for (int k = 0; k < 6; k++) a.rootH[k] = c->rootH[k];
     for (int k = 0; k < 3; k++) a.lastC[k] = c->lastC[k];
@@ -265,6 +276,14 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
+    } else if (ctx->dTreelets) {
+        if (trav == 1) {
+            if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_tree<MODE_RAYS, ANYHIT, false, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_tree<MODE, ANYHIT, false, false>), grid, block, 0, stream, a);
+        } else {
+            if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_tree<MODE_RAYS, ANYHIT, true, true>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_tree<MODE, ANYHIT, true, false>), grid, block, 0, stream, a);
+        }
     } else if (ctx->compact) {
         if (trav == 1) {
             if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, false, true, true>), grid, block, 0, stream, a);
@@ -471,7 +490,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_PERSIST_BLOCKS: if (value < 1 || value > 8) return ctx->fail(-1, "PT_OPT_PERSIST_BLOCKS must be 1..8"); ctx->optBlocksPerCU = value; ctx->userBlocks = true; return 0;
         case PT_OPT_REFILL_MIN: if (value < 1 || value > 64) return ctx->fail(-1, "PT_OPT_REFILL_MIN must be 1..64"); ctx->optRefillMin = value; ctx->userRefill = true; return 0;
         case PT_OPT_CLAIM_CHUNK: if (value < 0 || value > 1024 || value % 64) return ctx->fail(-1, "PT_OPT_CLAIM_CHUNK must be 0 or a multiple of 64 up to 1024"); ctx->optClaimChunk = value; return 0;
-        case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0 or 1"); ctx->optRecordLayout = value; return 0;
+        case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0, 1 or 2"); ctx->optRecordLayout = value; return 0;
         case PT_OPT_SORT_BITS: if (value < 1 || value > 4) return ctx->fail(-1, "PT_OPT_SORT_BITS must be 1..4"); ctx->optSortBits = value; return 0;
         case PT_OPT_SORT_RAYS: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SORT_RAYS must be 0, 1 or 2"); ctx->optSortRays = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
@@ -531,6 +550,18 @@ try {
             return ctx->fail(-1, ebuf);
     }
     ctx->maxStack = maxStack;
+    std::vector<unsigned char> tl; uint64_t tlUnits = 0; uint32_t tlStack = 0;
+    if (ctx->optRecordLayout == 2 && T > 1) {
+        float rb[6];
+        int rc = pt_flatten_bvh_treelets(nodes, N, positions, indices, T, nullptr, 0, &tlUnits, rb, &tlStack, ebuf, sizeof(ebuf));
+        if (rc < 0) return ctx->fail(-1, ebuf);
+        if (rc == 0) {
+            tl.resize((size_t)tlUnits * 64 + 64);          /* one spare unit: a 128 B fetch may start at the last leaf */
+            rc = pt_flatten_bvh_treelets(nodes, N, positions, indices, T, tl.data(), tlUnits, &tlUnits, rb, &tlStack, ebuf, sizeof(ebuf));
+            if (rc < 0) return ctx->fail(-1, ebuf);
+        }
+        if (rc != 0) { tl.clear(); tlUnits = 0; tlStack = 0; }          /* a box that does not fit the encoding: 64 B records only */
+    }
     /* the certified walk skips a subtree when the ray enters its box beyond max_t, which is sound only if everything in the
        subtree lies inside that box: true of every tree pt_build_bvh makes, checked here because the array is the caller's */
     ctx->boxesNest = true;
@@ -576,6 +607,11 @@ try {
     } else {
         if (T > 1) HIPCHK(hipMemcpy(ctx->dRecords, n2.data(), interiorBytes, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy((char*)ctx->dRecords + interiorBytes, tr.data(), (size_t)T * recSize, hipMemcpyHostToDevice));
+    }
+    if (!tl.empty()) {
+        HIPCHK(hipMalloc((void**)&ctx->dTreelets, tl.size()));
+        HIPCHK(hipMemcpy(ctx->dTreelets, tl.data(), tl.size(), hipMemcpyHostToDevice));
+        ctx->treeletBytes = (uint32_t)((size_t)tlUnits * 64); ctx->treeletMaxStack = tlStack;
     }
     if (ctx->compact) {
         HIPCHK(hipMalloc((void**)&ctx->dLeafRef, (size_t)T * 4));
@@ -1021,7 +1057,7 @@ PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t n
     BatchScratch sc;
     /* the spill area holds (tree depth - LDS part) entries per lane of the launch: the launch takes as many workgroups
        as fit, up to its usual number; a tree too deep for even one workgroup per CU is refused */
-    sc.spillEntries = ctx->maxStack > PT_STACK_LDS ? ctx->maxStack - PT_STACK_LDS : 0;
+    sc.spillEntries = spill_entries(ctx);
     sc.maxBlocks = ctx->numCUs * 8;
     if (sc.spillEntries) {
         const size_t perBlock = (size_t)sc.spillEntries * PT_BLOCK * sizeof(uint2);

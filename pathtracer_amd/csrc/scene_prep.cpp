@@ -283,3 +283,131 @@ extern "C" PT_API void pt_fill_constants(PtShaderConstants* c, uint32_t width, u
     c->numRays = num_rays; c->numBVHNodes = num_bvh_nodes;
     c->ambientRadiance[0] = ambient[0]; c->ambientRadiance[1] = ambient[1]; c->ambientRadiance[2] = ambient[2];
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The flattening pass with two-level treelet records (PtTreelet): records and leaves in one
+ * depth-first stream of 64 B units.
+ * ---------------------------------------------------------------------------------------- */
+namespace {
+
+/* One box of a pair: digest + 5-bit differences.  False if f16(b-c) cannot be rebuilt from f16(a-c). */
+bool encode_half(const PtBVHNode& n, PtTreeletPair& o, int s)
+{
+    float c[3]; uint16_t h[6];
+    digest_box(n, c, h);
+    for (int k = 0; k < 3; k++) {
+        o.c[k][s] = c[k];
+        o.hA[k][s] = h[k];
+        const int d = (int)h[3 + k] - (int)(h[k] & 0x7FFFu);
+        if ((h[3 + k] & 0x8000u) || d < -15 || d > 15) return false;
+        o.delta |= (uint32_t)(d + 15) << (5 * k + 16 * s);
+    }
+    return true;
+}
+
+enum : uint64_t { TREELET_OFF_LIMIT = 1ull << 21, TREELET_BIG_STEP = 32 };
+
+}  // namespace
+
+extern "C" PT_API int pt_flatten_bvh_treelets(const PtBVHNode* nodes, uint32_t num_nodes, const float* positions, const uint32_t* indices,
+                                              uint32_t num_triangles, void* units, uint64_t capacity_units, uint64_t* num_units,
+                                              float* root_box, uint32_t* max_stack, char* err, size_t err_len)
+try {
+    if (!nodes || !positions || !indices || !num_units) { set_err(err, err_len, "pt_flatten_bvh_treelets: null argument"); return -1; }
+    if (const char* why = validate_tree(nodes, num_nodes, num_triangles)) { set_err(err, err_len, (std::string("pt_flatten_bvh_treelets: ") + why).c_str()); return -3; }
+    const uint32_t N = num_nodes;
+    auto is_leaf = [&](uint32_t i) { return nodes[i].right <= 0; };
+    auto subtree_nodes = [&](uint32_t i) { const uint32_t e = nodes[i].next ? (uint32_t)nodes[i].next : N; return (uint64_t)(e - i); };
+
+    /* pass 1: where every leaf and every treelet root goes.  Depth first: a root's record, then the subtrees of its
+       targets in order, so that the first target starts right behind the record. */
+    std::vector<uint32_t> unitOf(N, 0xFFFFFFFFu);
+    struct Frame { uint32_t node, u; int k, nt; uint32_t tgt[4]; bool big; };
+    std::vector<Frame> st;
+    uint64_t pos = 0;
+    size_t deepest = 0;
+    auto open = [&](uint32_t i) {
+        if (is_leaf(i)) { unitOf[i] = (uint32_t)pos++; return; }
+        if (pos & 1) pos++;                                   /* records start on a 128 B line */
+        Frame f; f.node = i; f.u = (uint32_t)pos; pos += 2; f.k = 0; f.nt = 0;
+        unitOf[i] = f.u;
+        const uint32_t L = i + 1, R = (uint32_t)nodes[i].right;
+        if (is_leaf(L)) f.tgt[f.nt++] = L; else { f.tgt[f.nt++] = L + 1; f.tgt[f.nt++] = (uint32_t)nodes[L].right; }
+        if (is_leaf(R)) f.tgt[f.nt++] = R; else { f.tgt[f.nt++] = R + 1; f.tgt[f.nt++] = (uint32_t)nodes[R].right; }
+        /* at most three units per node (a record and its padding, or a leaf), plus the padding of the few big records above */
+        f.big = 3 * subtree_nodes(i) + 8192 >= TREELET_OFF_LIMIT;
+        st.push_back(f);
+        if (st.size() > deepest) deepest = st.size();
+    };
+    open(0);
+    while (!st.empty()) {
+        Frame& f = st.back();
+        if (f.k == f.nt) { st.pop_back(); continue; }
+        const int k = f.k++;
+        const uint32_t t = f.tgt[k], u = f.u;
+        if (f.big && k > 0) while ((pos - u) % TREELET_BIG_STEP) pos++;
+        open(t);                                              /* may grow the stack: f is not used after this */
+    }
+    if (pos >= (1ull << 26)) { set_err(err, err_len, "pt_flatten_bvh_treelets: more than 2^26 units (4 GiB) of records"); return -2; }
+    *num_units = pos;
+    if (max_stack) *max_stack = (uint32_t)(3 * deepest);      /* a level of the walk leaves at most three entries behind */
+    if (root_box) { for (int k = 0; k < 3; k++) { root_box[k] = nodes[0].a[k]; root_box[3 + k] = nodes[0].b[k]; } }
+    if (!units) return 0;
+    if (capacity_units < pos) { set_err(err, err_len, "pt_flatten_bvh_treelets: output too small"); return -1; }
+
+    /* pass 2: fill */
+    unsigned char* out = (unsigned char*)units;
+    memset(out, 0, (size_t)pos * 64);
+    for (uint32_t i = 0; i < N; i++) {
+        if (unitOf[i] == 0xFFFFFFFFu) continue;               /* an interior node that lives inside its parent's record */
+        if (is_leaf(i)) {
+            PtTri o; memset(&o, 0, sizeof(o));
+            const uint32_t t = (uint32_t)(-nodes[i].right) / 3u;
+            const uint32_t i1 = indices[3 * (size_t)t], i2 = indices[3 * (size_t)t + 1], i3 = indices[3 * (size_t)t + 2];
+            const float* p1 = positions + 4 * (size_t)i1; const float* p2 = positions + 4 * (size_t)i2; const float* p3 = positions + 4 * (size_t)i3;
+            for (int k = 0; k < 3; k++) { o.p1[k] = p1[k]; o.e1[k] = p2[k] - p1[k]; o.e2[k] = p3[k] - p1[k]; }   /* intersections.glsl:34-35 */
+            o.i1 = (int32_t)i1; o.i2 = (int32_t)i2; o.i3 = (int32_t)i3;
+            o.refLeaf = i;
+            o.flags = (i == N - 1) ? 1u : 0u;
+            memcpy(out + (size_t)unitOf[i] * 64, &o, 64);
+            continue;
+        }
+        PtTreelet o; memset(&o, 0, sizeof(o));
+        const uint32_t u = unitOf[i], L = i + 1, R = (uint32_t)nodes[i].right;
+        bool ok = encode_half(nodes[L], o.pair[0], 0) && encode_half(nodes[R], o.pair[0], 1);
+        uint32_t tgt[4] = { 0, 0, 0, 0 }; bool have[4] = { false, false, false, false };
+        if (is_leaf(L)) { o.pair[0].delta |= 1u << 15; tgt[0] = L; have[0] = true; }
+        else {
+            const uint32_t a = L + 1, b = (uint32_t)nodes[L].right;
+            ok = ok && encode_half(nodes[a], o.pair[1], 0) && encode_half(nodes[b], o.pair[1], 1);
+            if (is_leaf(a)) o.pair[1].delta |= 1u << 15;
+            if (is_leaf(b)) o.pair[1].delta |= 1u << 31;
+            tgt[0] = a; tgt[1] = b; have[0] = have[1] = true;
+        }
+        if (is_leaf(R)) { o.pair[0].delta |= 1u << 31; tgt[2] = R; have[2] = true; }
+        else {
+            const uint32_t a = R + 1, b = (uint32_t)nodes[R].right;
+            ok = ok && encode_half(nodes[a], o.pair[2], 0) && encode_half(nodes[b], o.pair[2], 1);
+            if (is_leaf(a)) o.pair[2].delta |= 1u << 15;
+            if (is_leaf(b)) o.pair[2].delta |= 1u << 31;
+            tgt[2] = a; tgt[3] = b; have[2] = have[3] = true;
+        }
+        if (!ok) { set_err(err, err_len, "pt_flatten_bvh_treelets: a box does not fit the treelet encoding"); return 1; }
+        if (unitOf[tgt[0]] != u + 2) { set_err(err, err_len, "pt_flatten_bvh_treelets: internal error (first target is not behind its record)"); return -5; }
+        uint64_t off[4] = { 0, 0, 0, 0 };
+        bool big = false;
+        for (int k = 1; k < 4; k++) if (have[k]) { off[k] = (uint64_t)unitOf[tgt[k]] - u; if (off[k] >= TREELET_OFF_LIMIT) big = true; }
+        if (big) {
+            for (int k = 1; k < 4; k++) {
+                if (off[k] % TREELET_BIG_STEP || off[k] / TREELET_BIG_STEP >= TREELET_OFF_LIMIT) {
+                    set_err(err, err_len, "pt_flatten_bvh_treelets: internal error (a subtree start does not fit its link)"); return -5;
+                }
+                off[k] /= TREELET_BIG_STEP;
+            }
+        }
+        const uint64_t link = off[1] | (off[2] << 21) | (off[3] << 42) | (big ? 1ull << 63 : 0ull);
+        o.link[0] = (uint32_t)link; o.link[1] = (uint32_t)(link >> 32);
+        memcpy(out + (size_t)u * 64, &o, 128);
+    }
+    return 0;
+} catch (...) { set_err(err, err_len, "pt_flatten_bvh_treelets: out of memory"); return -4; }

@@ -51,12 +51,13 @@ def courtyard_small():
     return dict(positions=pos, aux=aux, indices_in=idx, nodes=nodes, indices=ridx, depth=depth)
 
 
-@pytest.fixture(scope="session", params=["records64", "records48"])
+@pytest.fixture(scope="session", params=["records64", "records48", "treelets"])
 def gpu_ctx(request):
-    """One context per record layout: every GPU test runs on the 64 B records (the default) and on the 48 B records."""
+    """One context per record layout: every GPU test runs on the 64 B records, on the 48 B records and on the 128 B
+    two-level treelet records."""
     import pathtracer_amd as pt
     from pathtracer_amd import core
     ctx = pt.PathTracer(0)
-    ctx.set_option(core.OPT_RECORD_LAYOUT, 1 if request.param == "records48" else 0)
+    ctx.set_option(core.OPT_RECORD_LAYOUT, {"records64": 0, "records48": 1, "treelets": 2}[request.param])
     yield ctx
     ctx.close()

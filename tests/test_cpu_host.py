@@ -374,3 +374,102 @@ def test_bvh_builder_bit_identical_on_random_soups(oracle_lib, kind):
             onodes, oridx, odepth = oracle.build_bvh(pos, idx)
             assert np.array_equal(nodes.view(np.uint8), onodes.view(np.uint8)), (kind, n, threads)
             assert np.array_equal(ridx, oridx) and depth == odepth
+
+
+def _decode_treelet_stream(units, num_nodes):
+    """Walks the depth-first stream of 64 B units from unit 0 the way the kernel's references do (first target behind
+    the record, the other three through the link words) and returns the nodes it finds in the reference tree's
+    pre-order - ("box", (c[3] f32, hA[3] u16, hB[3] u16 rebuilt from the 5-bit differences), is_leaf) per node below
+    the root, ("leaf", 64 B record) after each leaf's box - plus the deepest level of records on any path."""
+    flat = units.reshape(-1)
+    out, deepest = [], [0]
+
+    def half(pair, s):
+        hA = pair["hA"][:, s].copy()
+        hB = np.array([(int(hA[k]) & 0x7FFF) + ((int(pair["delta"]) >> (5 * k + 16 * s)) & 31) - 15 for k in range(3)], dtype=np.uint16)
+        return pair["c"][:, s].copy(), hA, hB
+
+    def target(is_leaf, u, level):
+        if is_leaf:
+            out.append(("leaf", flat[u * 16:u * 16 + 16].view(core.TRI_DT)[0]))
+        else:
+            visit(u, level)
+
+    def visit(u, level):
+        assert u % 2 == 0, "a record does not start on a 128 B line"
+        deepest[0] = max(deepest[0], level)
+        r = flat[u * 16:u * 16 + 32].view(core.TREELET_DT)[0]
+        link = int(r["link"][0]) | (int(r["link"][1]) << 32)
+        sh = 5 if link >> 63 else 0
+        starts = [u + 2] + [u + (((link >> (21 * k)) & 0x1FFFFF) << sh) for k in range(3)]
+        d = [int(r["pair"][k]["delta"]) for k in range(3)]
+        for side, bit, pair, st in ((0, 0x8000, 1, starts[0:2]), (1, 0x80000000, 2, starts[2:4])):
+            half_is_leaf = bool(d[0] & bit)
+            out.append(("box", half(r["pair"][0], side), half_is_leaf))
+            if half_is_leaf:
+                target(True, st[0], level + 1)
+            else:
+                for s2, bit2 in ((0, 0x8000), (1, 0x80000000)):
+                    child_is_leaf = bool(d[pair] & bit2)
+                    out.append(("box", half(r["pair"][pair], s2), child_is_leaf))
+                    target(child_is_leaf, st[s2], level + 1)
+
+    visit(0, 1)
+    return out, deepest[0]
+
+
+@pytest.mark.parametrize("fixture", ["monkey", "bunny"])
+def test_treelet_stream_is_the_reference_tree(request, fixture):
+    """The 128 B treelet layout holds the reference tree, box for box and leaf for leaf: walking the stream through its
+    own links visits the nodes in the reference's pre-order; every box decodes (centre, f16(a-c), f16(b-c) rebuilt from
+    the 5-bit difference as the kernel rebuilds it) to the digest of that reference node's box; every leaf unit is the
+    64 B leaf record of the two-box layout; records sit on 128 B lines; and the stack bound covers the deepest path."""
+    m = request.getfixturevalue(fixture)
+    nodes = m["nodes"]
+    out = pt.flatten_bvh_treelets(nodes, m["positions"], m["indices"])
+    assert out is not None
+    units, rb, max_stack = out
+    n2, tr, rb2, ms2 = pt.flatten_bvh(nodes, m["positions"], m["indices"])
+    assert np.array_equal(rb, rb2)
+    walk, deepest = _decode_treelet_stream(units, nodes.shape[0])
+    assert max_stack == 3 * deepest and max_stack >= ms2
+    # the walk lists every node but the root: a "box" entry per node in pre-order, a "leaf" entry after each leaf's box
+    boxes = [w for w in walk if w[0] == "box"]
+    leaves = [w[1] for w in walk if w[0] == "leaf"]
+    assert len(boxes) == nodes.shape[0] - 1 and len(leaves) == m["indices"].shape[0]
+    c = (nodes["a"] + nodes["b"]) * np.float32(0.5)
+    hA = (nodes["a"] - c).astype(np.float16).view(np.uint16)
+    hB = (nodes["b"] - c).astype(np.float16).view(np.uint16)
+    for i, (_, (bc, ba, bb), is_leaf) in enumerate(boxes, start=1):
+        assert np.array_equal(bc, c[i]) and np.array_equal(ba, hA[i]) and np.array_equal(bb, hB[i]), f"box of node {i}"
+        assert is_leaf == (nodes["right"][i] <= 0)
+    order = [int(-nodes["right"][i]) // 3 for i in range(nodes.shape[0]) if nodes["right"][i] <= 0]      # leaves in pre-order
+    for leaf, t in zip(leaves, order):
+        assert leaf.tobytes() == tr[t].tobytes()
+    assert units.shape[0] <= 3 * nodes.shape[0]
+
+
+def test_treelet_pass_small_trees_and_refusals(bunny):
+    """One, two and three triangles (a root that is a leaf, a record with two leaf halves, a record with one interior
+    half), a box the 5-bit difference cannot hold, and a malformed tree."""
+    for n in (1, 2, 3, 4, 5):
+        pos = np.ones((3 * n, 4), np.float32)
+        pos[:, :3] = np.random.default_rng(n).uniform(-1, 1, (3 * n, 3))
+        idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        nodes, ridx, _ = pt.build_bvh(pos, idx, 1)
+        out = pt.flatten_bvh_treelets(nodes, pos, ridx)
+        assert out is not None
+        units, _, ms = out
+        walk, deepest = _decode_treelet_stream(units, nodes.shape[0]) if n > 1 else ([], 0)
+        if n == 1:
+            assert units.shape[0] == 1 and ms == 0
+        else:
+            assert sum(1 for w in walk if w[0] == "leaf") == n and ms == 3 * deepest
+    nodes = bunny["nodes"].copy()
+    k = int(np.nonzero(nodes["right"] > 0)[0][3]) + 1
+    nodes["a"][k] = (4096.0, 0.0, 0.0)
+    nodes["b"][k] = (4096.0 + 2.0 ** -11 * 3, 1.0, 1.0)
+    assert pt.flatten_bvh_treelets(nodes, bunny["positions"], bunny["indices"]) is None
+    bad = bunny["nodes"].copy(); bad["next"][5] = 3
+    with pytest.raises(pt.PtError):
+        pt.flatten_bvh_treelets(bad, bunny["positions"], bunny["indices"])

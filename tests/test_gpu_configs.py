@@ -163,3 +163,32 @@ def test_sample_partition_sums_to_the_single_context_image(san_miguel, size):
         for c in ranks:
             c.close()
         single.close()
+
+
+def test_treelet_layout_equals_two_box_layout_at_scale(san_miguel):
+    """The 128 B two-level treelet records against the 64 B two-box records on the 5.8 M-triangle stand-in, 2^24
+    incoherent rays: hits (ids and t) byte for byte in the reference-order walk and in the near-child-first walk,
+    closest-hit and any-hit (the walk visits the same leaves in the same order with the same max_t in both layouts)."""
+    n = 1 << 24
+    out = {}
+    for layout in (core.LAYOUT_RECORDS64, core.LAYOUT_TREELETS):
+        c = pt.PathTracer(0)
+        try:
+            c.set_option(core.OPT_RECORD_LAYOUT, layout)
+            helpers.upload(c, san_miguel)
+            d_rays, d_hits = c.alloc(n * 32), c.alloc(n * 16)
+            c.generate_rays(d_rays, n, seed=5)
+            for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED):
+                c.set_option(core.OPT_TRAVERSAL, trav)
+                for any_hit in (False, True):
+                    m = n if trav == core.TRAVERSAL_FLAT_ORDERED else n // 4        # the reference order is the slow one
+                    c.trace_rays_device(d_rays, m, d_hits, any_hit=any_hit)
+                    out[(layout, trav, any_hit)] = d_hits.to_host(pt.HIT_DT, m)
+            d_rays.free(); d_hits.free()
+        finally:
+            c.close()
+    for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED):
+        for any_hit in (False, True):
+            a, b = out[(core.LAYOUT_RECORDS64, trav, any_hit)], out[(core.LAYOUT_TREELETS, trav, any_hit)]
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"traversal {trav}, any_hit {any_hit}: {int((a != b).sum())} hits differ"
+            assert 0.5 < (a["i1"] >= 0).mean() < 0.95

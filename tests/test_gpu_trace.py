@@ -98,7 +98,10 @@ def test_ordered_traversal_within_bar(gpu_ctx, oracle_lib, request, model_name):
 
 
 def test_stats_match_oracle_counts(gpu_ctx, oracle_lib, bunny):
-    """The counting build reports exactly the box and triangle tests the reference walk performs."""
+    """The counting build reports exactly the box and triangle tests the reference walk performs.  (The treelet walk
+    tests the boxes of a node's grandchildren together with its children's, before it knows whether it will enter
+    them: the same triangle tests, at least as many box tests.)"""
+    treelets = gpu_ctx.get_option(core.OPT_RECORD_LAYOUT) == core.LAYOUT_TREELETS
     helpers.upload(gpu_ctx, bunny)
     osc = helpers.oracle_scene(bunny)
     rays = helpers.random_rays(bunny["nodes"][0]["a"], bunny["nodes"][0]["b"], 50_000, seed=2)
@@ -108,7 +111,10 @@ def test_stats_match_oracle_counts(gpu_ctx, oracle_lib, bunny):
         _, st = gpu_ctx.trace_rays(rays, want_stats=True)
         assert int(st[3]) == len(rays)
         assert int(st[1]) == int(cnt[1]), (trav, st, cnt)
-        assert int(st[0]) == int(cnt[0]), (trav, st, cnt)
+        if treelets and trav == core.TRAVERSAL_FLAT:
+            assert int(cnt[0]) <= int(st[0]) <= 3 * int(cnt[0]), (trav, st, cnt)
+        else:
+            assert int(st[0]) == int(cnt[0]), (trav, st, cnt)
 
 
 def test_edge_cases(gpu_ctx, oracle_lib, bunny):
