@@ -3,7 +3,7 @@
  *
  * Every lane fetches one 64 B record per step (four buffer_load_dwordx4, as k_trace_flat does) at an address the
  * previous record named.  A step goes to the HOT set (1 MB: stays in every XCD's L2, far larger than the 32 KB L1)
- * with probability h and otherwise follows a random cycle through the whole table (742 MB: an L2 miss).  Which of the
+ * with probability h and otherwise to a record anywhere in the whole table (742 MB: an L2 miss), named by the loaded word.  Which of the
  * two a lane takes is drawn per lane and step, so the lanes of a wavefront mix both kinds in one load instruction, as
  * the traversal kernel's lanes do.  For each h the time is set beside two models built from the pure streams:
  *   sum:  t = n_miss / R_miss + n_hit / R_hit      (the two paths take turns)
@@ -39,8 +39,13 @@ __global__ __launch_bounds__(256) void k_mix(const uint4* records, uint32_t byte
         u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
         u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
         asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
-        const bool hot = mix32(gid * 977u + s) < hotThreshold;       /* the NEXT record is a hot one */
-        idx = hot ? q0.y : q0.x;
+        const uint32_t rnd = mix32(gid * 977u + s);
+        const bool hot = rnd < hotThreshold;                         /* the NEXT record is a hot one */
+        /* a cold step lands anywhere in the table: the loaded word (so the step depends on the fetch) scrambled with a
+           per-lane, per-step number (or the cold steps that follow a hot record would always land on the same few
+           records, which would then sit in the L2 too) */
+        const uint32_t cold = __umulhi(mix32(q0.x ^ (rnd * 0x9E3779B9u)), n);
+        idx = hot ? q0.y : cold;
         nHot += hot ? 1u : 0u;
         acc += q1.y + q2.z + q3.w;
     }
