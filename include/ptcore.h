@@ -273,6 +273,12 @@ enum {
                                     tracing it (results are stored under the rays' own indices and do not change):
                                     0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
     PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 4): the ordering grid has 2^bits cells per axis */
+    PT_OPT_SECOND_WALK    = 11,  /* how PT_OPT_TRAVERSAL = 3 walks the rays its first pass lists, in reference order: 0 = one
+                                    ray per lane (the walk of traversal 1); 1 (default) = one ray per wavefront, 64 nodes of
+                                    the reference array fetched and box-tested at a time.  Same hits, bit for bit */
+    PT_OPT_SHADOW_STREAM  = 12,  /* 1 (default): inside pt_render_sample[s] the shadow pass of depth d runs on a second stream
+                                    beside the closest-hit pass of depth d+1; 0: on the frame's own stream, after the shade
+                                    pass (half as many streams: for hosts that are short of hardware queues) */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and pair of streams; results do not depend on it.  Three frames are six
                                     streams, and HIP gives a process four hardware queues unless the environment

@@ -620,11 +620,15 @@ PO_API void po_launch(const PoScene* sc, PoFrame* f, const PtShaderConstants* c,
         }
 }
 
-/* trace.comp:58-163.  Returns false when the path ends here. */
-static bool shadeHit(const PoScene& sc, PoFrame& f, const PtShaderConstants& c, Rng& rng, F3 hitPos, const Intersection& isect, Ray& r,
-                     h16 albedo[4], h16 wIn[3], h16& prob, int flags)
+/* What shadeHit holds when it reaches its shadow walk (trace.comp:123). */
+struct ShadeState {
+    h16 albedo[4]; H3 normal, rd16, lightRadiance; h16 falloff; F3 lightDir, hitPos; Ray rLight;
+};
+
+/* trace.comp:58-121: everything before the shadow walk. */
+static void shadeHitBefore(const PoScene& sc, const PtShaderConstants& c, Rng& rng, F3 hitPos, const Intersection& isect, const Ray& r, ShadeState& st)
 {
-    wIn[0] = wIn[1] = wIn[2] = f2h(0.0f);
+    h16* albedo = st.albedo;
     const PtVertexAux& v1 = sc.aux[isect.i1]; const PtVertexAux& v2 = sc.aux[isect.i2]; const PtVertexAux& v3 = sc.aux[isect.i3];
     const h16 inv255 = hdiv(f2h(1.0f), f2h(255.0f));
     h16 bx = isect.bary.x, by = isect.bary.y, bz = isect.bary.z;
@@ -664,10 +668,20 @@ static bool shadeHit(const PoScene& sc, PoFrame& f, const PtShaderConstants& c, 
     }
     rLight.o = hitPos; rLight.d = lightDir; rLight.origBvhId = r.origBvhId;
     rLight.rcpD = rcp_dir(lightDir); rLight.min_t = 0.001f;
+    st.normal = normal; st.rd16 = rd16; st.lightRadiance = lightRadiance; st.falloff = falloff; st.lightDir = lightDir; st.hitPos = hitPos;
+    st.rLight = rLight;
+}
 
-    Intersection isectDL{};
-    f.shadowRays++;
-    if (!traceRayFast(sc, rLight, isectDL, true, flags, &f.counters)) {                     /* trace.comp:123-130 */
+/* trace.comp:123-163: from the shadow walk's verdict on.  Returns false when the path ends here. */
+static bool shadeHitAfter(const PtShaderConstants& c, Rng& rng, const ShadeState& st, bool occluded, Ray& r, h16 albedo[4], h16 wIn[3], h16& prob)
+{
+    (void)c;
+    wIn[0] = wIn[1] = wIn[2] = f2h(0.0f);
+    for (int k = 0; k < 4; k++) albedo[k] = st.albedo[k];
+    const H3 normal = st.normal, rd16 = st.rd16, lightRadiance = st.lightRadiance;
+    const h16 falloff = st.falloff;
+    const F3 lightDir = st.lightDir, hitPos = st.hitPos;
+    if (!occluded) {                                                                        /* trace.comp:123-130 */
         h16 lr[3] = { lightRadiance.x, lightRadiance.y, lightRadiance.z };
         if (h2f(albedo[3]) > 0.5f) {
             for (int k = 0; k < 3; k++) wIn[k] = hadd(wIn[k], hmul(hmul(hmul(f2h(2.0f), falloff), albedo[k]), lr[k]));

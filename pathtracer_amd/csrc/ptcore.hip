@@ -152,7 +152,7 @@ struct PtContext {
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 1;
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
@@ -330,7 +330,14 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
     HIPCHK(hipGetLastError());
     TraceArgs b = a;
     b.order = flag; b.countPtr = ctr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
-    return launch_trace<MODE, false>(ctx, b, count, stream, area, fixed);        /* traversal 3 maps to the reference-order walk there */
+    if (ctx->optSecondWalk == 0)
+        return launch_trace<MODE, false>(ctx, b, count, stream, area, fixed);    /* traversal 3 maps to the reference-order walk there */
+    /* the listed rays are few and their walks long: one wavefront per ray (k_trace_ref_wave); no stack, no spill area */
+    dim3 grid2(ctx->numCUs * 2);
+    if (count) hipLaunchKernelGGL((k_trace_ref_wave<MODE, true>), grid2, block, 0, stream, b);
+    else hipLaunchKernelGGL((k_trace_ref_wave<MODE, false>), grid2, block, 0, stream, b);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 int check_scene(PtContext* ctx) { return ctx->T ? 0 : ctx->fail(-2, "no scene uploaded (call pt_scene_upload first)"); }
@@ -493,6 +500,8 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0, 1 or 2"); ctx->optRecordLayout = value; return 0;
         case PT_OPT_SORT_BITS: if (value < 1 || value > 4) return ctx->fail(-1, "PT_OPT_SORT_BITS must be 1..4"); ctx->optSortBits = value; return 0;
         case PT_OPT_SORT_RAYS: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SORT_RAYS must be 0, 1 or 2"); ctx->optSortRays = value; return 0;
+        case PT_OPT_SHADOW_STREAM: ctx->optShadowStream = value != 0; return 0;
+        case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
     }
@@ -508,6 +517,8 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_REFILL_MIN: *value = ctx->optRefillMin; return 0;
         case PT_OPT_CLAIM_CHUNK: *value = ctx->optClaimChunk; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: *value = ctx->optFramesInFlight; return 0;
+        case PT_OPT_SECOND_WALK: *value = ctx->optSecondWalk; return 0;
+        case PT_OPT_SHADOW_STREAM: *value = ctx->optShadowStream; return 0;
         case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
         case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;
         case PT_OPT_RECORD_LAYOUT: *value = ctx->optRecordLayout; return 0;
@@ -754,7 +765,7 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
     TraceArgs s; fill_trace_args(ctx, s);
     s.stack = p.dStack; s.shadowRays = p.dShadow[q];
     s.countPtr = shadowCtr; s.fetchCounter = shadowCtr + 1;
-    if (overlapped) {
+    if (overlapped && ctx->optShadowStream) {
         HIPCHK(hipEventRecord(p.evShade[q], p.stream));
         HIPCHK(hipStreamWaitEvent(p.stream2, p.evShade[q], 0));
         if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, p.stream2, 2 * p.index + 1)) return rc;

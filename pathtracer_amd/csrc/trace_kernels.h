@@ -331,6 +331,115 @@ __global__ __launch_bounds__(64) void k_trace_ref_speculative(TraceArgs a, uint3
     store_result<MODE_JOBS>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, ranOff ? hitIndex : 0u);
 }
 
+/* The reference-order walk with one WAVEFRONT per ray, for the few rays the certified walk hands back: a list that short
+ * is all latency (the walk of its longest ray, one dependent fetch per node), so the 64 lanes work on one ray instead.
+ * The reference's array is in pre-order with skip links, so wherever the walk stands, the nodes it can visit next are the
+ * ones right behind it: lane l fetches node index + l (one coalesced 2 KB read) and runs the max_t-independent part of
+ * its box test; the walk through those 64 nodes - enter and go to the next node, or fail and follow the skip link - is
+ * then a chase through registers (a scalar loop over v_readlane), no memory involved.  Every leaf on that path tests its
+ * triangle in its own lane, all at once, acceptance left open; the first of them, in walk order, that the reference
+ * would accept (t <= max_t of that moment: nothing before it on the path changed max_t) shrinks max_t, and the chase is
+ * redone from the node behind it with the boxes and triangle results already in registers.  When the path leaves the
+ * window the next 64 nodes are fetched from where it went.  Node for node this is the loop of intersections.glsl:64-111
+ * with the arithmetic of k_trace_ref; closest hit only, rays from a.order (the list) or in batch order. */
+template <int MODE, bool COUNT>      /* MODE_RAYS or MODE_JOBS */
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+    enum : uint32_t { SUCC_NEXT_WINDOW = 64, SUCC_JUMP = 65, SUCC_END = 66, SUCC_RAN_OFF = 67 };
+    /* Everything a wavefront decides here it decides for all its lanes: no lane may leave a loop or skip a block on its
+       own, or the votes and lane reads below would run without it (a version that let lane 0 alone claim the ray and
+       store the result had the compiler send the other 63 lanes round the loop without it).  Hence rays are dealt to
+       wavefronts by stride, not by an atomic, and every lane stores the (same) result. */
+    const uint32_t numWaves = gridDim.x * PT_WAVES_PER_BLOCK;
+    const uint32_t firstRay = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PT_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+    for (uint64_t k = firstRay; k < total; k += numWaves) {
+        const uint64_t id = a.order ? (uint64_t)a.order[k] : k;
+        RayRegs r; uint32_t exclude = 0, tag = 0;
+        if (load_ray<MODE>(a, id, r, exclude, tag)) {                   /* the same for all lanes: one ray per wavefront */
+        if (COUNT) nRay++;
+        uint32_t index = 0, hitIndex = 0;
+        bool hit = false, ranOff = false, ended = false;
+        int32_t i1 = -1, i2 = -1, i3 = -1; float alpha = 0, beta = 0, gamma = 0;
+
+        /* every window moves the walk forward by at least one node, every redone chase by at least one lane, every chase
+           step by at least one lane: the three loops end by themselves, and are bounded besides so that a malformed
+           array cannot hold a wavefront for ever */
+        for (uint32_t windows = 0; !ended && windows < a.numNodes; windows++) {
+            const uint32_t base = index, n = base + (uint32_t)lane;
+            const bool valid = n < a.numNodes;
+            float4 na = make_float4(0, 0, 0, 0), nb = na;
+            if (valid) { const float4* np = (const float4*)(a.nodes + n); na = np[0]; nb = np[1]; }
+            if (COUNT) nRec++;
+            float tmin = 0.0f;
+            bool s = false;
+            if (valid) {
+                const float cx = (na.x + nb.x) * 0.5f, cy = (na.y + nb.y) * 0.5f, cz = (na.z + nb.z) * 0.5f;
+                s = box_static(r, cx, cy, cz, (h16)(na.x - cx), (h16)(na.y - cy), (h16)(na.z - cz), (h16)(nb.x - cx), (h16)(nb.y - cy), (h16)(nb.z - cz), tmin);
+            }
+            const int32_t right = __float_as_int(nb.w);
+            const uint32_t nextAbs = (uint32_t)__float_as_int(na.w);
+            const uint64_t leafBits = __ballot(valid && right <= 0);
+            uint64_t triDone = 0;
+            float t = 0, al = 0, be = 0, ga = 0; bool ok0 = false; int32_t v1 = -1, v2 = -1, v3 = -1;
+            uint32_t p = 0;
+            for (int redo = 0; redo <= 64; redo++) {
+                /* where the walk goes from each node of the window, with the max_t of now */
+                const bool pass = s && r.max_t > tmin;
+                uint32_t succ;
+                if (pass) succ = (n + 1u >= a.numNodes) ? (uint32_t)SUCC_RAN_OFF : (uint32_t)lane + 1u;
+                else if (nextAbs == 0u) succ = SUCC_END;
+                else succ = (nextAbs - base < 64u) ? nextAbs - base : (uint32_t)SUCC_JUMP;
+                uint64_t visited = 0;
+                uint32_t q = p, last = p;
+                for (int hop = 0; hop < 64 && q < 64u; hop++) { visited |= 1ull << q; last = q; q = (uint32_t)__builtin_amdgcn_readlane((int)succ, (int)q); }
+                if (COUNT) nBox += (unsigned long long)__popcll(visited);
+                /* the leaves on that path test their triangles, each in its own lane; results are kept for a redone chase */
+                const uint64_t leafVisited = visited & leafBits & __ballot(pass);
+                const uint64_t need = leafVisited & ~triDone;
+                if ((need >> lane) & 1ull) {
+                    const uint32_t tri = (uint32_t)(-right) / 3u;
+                    const uint4* tp = a.tris + (size_t)tri * 4;
+                    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
+                    F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
+                    F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
+                    RayRegs open = r; open.max_t = __builtin_huge_valf();           /* acceptance against max_t is decided in walk order below */
+                    ok0 = tri_test(open, p1, e1, e2, t, al, be, ga);
+                    v1 = (int32_t)q0.w; v2 = (int32_t)q1.w; v3 = (int32_t)q2.w;
+                }
+                if (COUNT) nTri += (unsigned long long)__popcll(need);
+                triDone |= need;
+                const uint64_t accept = __ballot(((leafVisited >> lane) & 1ull) && ok0 && t <= r.max_t);
+                if (accept == 0) {                                     /* nothing on the path changes max_t: the walk leaves the window */
+                    if (q == SUCC_NEXT_WINDOW) index = base + 64u;
+                    else if (q == SUCC_JUMP) index = (uint32_t)__builtin_amdgcn_readlane((int)nextAbs, (int)last);
+                    else { ended = true; ranOff = q == SUCC_RAN_OFF; }
+                    break;
+                }
+                const int l = __ffsll((unsigned long long)accept) - 1;            /* the first leaf, in walk order, that the reference accepts */
+                r.max_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t), l));
+                alpha = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(al), l));
+                beta = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(be), l));
+                gamma = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ga), l));
+                i1 = __builtin_amdgcn_readlane(v1, l); i2 = __builtin_amdgcn_readlane(v2, l); i3 = __builtin_amdgcn_readlane(v3, l);
+                hit = true; hitIndex = base + (uint32_t)l;
+                /* the leaf's box passed, so the walk goes on at the node behind it, now with the smaller max_t */
+                if (base + (uint32_t)l + 1u >= a.numNodes) { ended = true; ranOff = true; break; }
+                p = (uint32_t)l + 1u;
+                if (p >= 64u) { index = base + 64u; break; }
+            }
+        }
+        store_result<MODE>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, ranOff ? hitIndex : 0u);
+        }
+    }
+    if (COUNT && lane == 0) {
+        atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
+    }
+}
+
 /* ---- flattened-layout walk -------------------------------------------------------------------- */
 
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
