@@ -557,6 +557,8 @@ enum {                                   /* behaviour switches of the frame func
                                             off = leave deeper slots stale as the reference does */
     PO_MODE_RESEED_EVERY_FRAME = 2,      /* launch seeds randState every frame instead of only after a clear */
     PO_MODE_KILL_ON_MISS = 4,            /* a missed ray's job is killed instead of re-traced each bounce (same image) */
+    PO_MODE_PLAIN_SHADOW_WALK = 8,       /* ANALYSIS ONLY, not the reference: in the SPECULATIVE build the shadow walk does not
+                                            vote.  Lets a test show that the vote in the shadow walk changes results */
 };
 
 PO_API PoFrame* po_frame_create(uint32_t W, uint32_t H, uint32_t slots)
@@ -717,20 +719,29 @@ static bool shadeHitAfter(const PtShaderConstants& c, Rng& rng, const ShadeState
     return true;
 }
 
-struct TraceJobState { uint32_t jobIndex, stackIndex, currentDepth; Rng rng; Ray r; Intersection isect; bool hit; bool live; };
+struct TraceJobState { uint32_t jobIndex, stackIndex, currentDepth; Rng rng; Ray r; Intersection isect; bool hit; bool live; ShadeState shade; };
 
-/* trace.comp:165-233 after the closest-hit walk */
-static void finishJob(const PoScene& sc, PoFrame& f, const PtShaderConstants& c, TraceJobState& j, int mode, int flags)
+/* trace.comp:192-212 up to the shadow walk inside shadeHit.  Returns false for a missed ray (nothing more to do). */
+static bool finishJobBefore(const PoScene& sc, PoFrame& f, const PtShaderConstants& c, TraceJobState& j, int mode)
 {
     PtRayStackSlot* stack = f.stack.data();
     if (!j.hit) {                                                                           /* trace.comp:192-196 */
         stack[j.stackIndex].prob = 0;
         if (mode & PO_MODE_KILL_ON_MISS) f.jobs[j.jobIndex] = PT_JOB_DEAD;
-        return;
+        return false;
     }
     F3 hitPos = { j.r.max_t * j.r.d.x + j.r.o.x, j.r.max_t * j.r.d.y + j.r.o.y, j.r.max_t * j.r.d.z + j.r.o.z };   /* :198 */
+    shadeHitBefore(sc, c, j.rng, hitPos, j.isect, j.r, j.shade);
+    f.shadowRays++;
+    return true;
+}
+
+/* the rest of shadeHit and trace.comp:212-233, given the shadow walk's verdict */
+static void finishJobAfter(PoFrame& f, const PtShaderConstants& c, TraceJobState& j, bool occluded, int mode)
+{
+    PtRayStackSlot* stack = f.stack.data();
     h16 albedo[4], wIn[3], prob = f2h(1.0f);
-    bool cont = shadeHit(sc, f, c, j.rng, hitPos, j.isect, j.r, albedo, wIn, prob, flags);
+    bool cont = shadeHitAfter(c, j.rng, j.shade, occluded, j.r, albedo, wIn, prob);
     if (cont && j.currentDepth != c.numRays - 1) {                                          /* trace.comp:212-223 */
         PtRayStackSlot& nx = stack[j.stackIndex + 1];
         nx.rayOrigin[0] = j.r.o.x; nx.rayOrigin[1] = j.r.o.y; nx.rayOrigin[2] = j.r.o.z;
@@ -791,6 +802,12 @@ PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, 
                     if (!js[k].live) continue;
                     f->closestRays++;
                     js[k].hit = traceRayFast(*sc, js[k].r, js[k].isect, false, flags, &f->counters);
+                    if (finishJobBefore(*sc, *f, *c, js[k], mode)) {
+                        Intersection isectDL{};
+                        Ray rl = js[k].shade.rLight;
+                        bool occluded = traceRayFast(*sc, rl, isectDL, true, flags, &f->counters);            /* trace.comp:123 */
+                        finishJobAfter(*f, *c, js[k], occluded, mode);
+                    }
                 }
             } else {
                 for (uint32_t base = 0; base < 64; base += subgroup) {
@@ -802,10 +819,20 @@ PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, 
                     f->closestRays += rr.size();
                     traceRayGroup(*sc, rr.data(), ii.data(), hv.data(), (int)rr.size(), false, true, flags, &f->counters);
                     for (size_t q = 0; q < rr.size(); q++) { js[who[q]].r = rr[q]; js[who[q]].isect = ii[q]; js[who[q]].hit = hv[q] != 0; }
+                    /* The whole of trace.comp is compiled with SPECULATIVE (CMakeLists.txt:33-36), so the vote of
+                       intersections.glsl:73-77 also governs the any-hit walk shadeHit makes (trace.comp:123).  Its
+                       subgroup is what is left of this one: the lanes whose ray hit (the others returned at
+                       trace.comp:194-195); a lane that finds an occluder returns and votes no more. */
+                    std::vector<Ray> sr; std::vector<Intersection> si; std::vector<int> sw;
+                    for (size_t q = 0; q < rr.size(); q++)
+                        if (finishJobBefore(*sc, *f, *c, js[who[q]], mode)) { sr.push_back(js[who[q]].shade.rLight); si.push_back(Intersection{}); sw.push_back(who[q]); }
+                    if (!sr.empty()) {
+                        std::vector<char> occ(sr.size());
+                        traceRayGroup(*sc, sr.data(), si.data(), occ.data(), (int)sr.size(), true, !(mode & PO_MODE_PLAIN_SHADOW_WALK), flags, &f->counters);
+                        for (size_t q = 0; q < sr.size(); q++) finishJobAfter(*f, *c, js[sw[q]], occ[q] != 0, mode);
+                    }
                 }
             }
-            for (uint32_t k = 0; k < 64; k++)
-                if (js[k].live) finishJob(*sc, *f, *c, js[k], mode, flags);
         }
 }
 

@@ -48,6 +48,9 @@ struct FrameArgs {
     const PtHitRec* hitRecs;
     PtShadowRay* shadowRays;         /* the shadow queue this depth appends to */
     uint32_t fuseCompact;            /* shade appends surviving jobs to jobsOut instead of rewriting jobs in place */
+    uint32_t tileShadow;             /* shade puts the shadow ray of pixel (x, y) at queue place tile * 64 + lane of the 8x8 tile
+                                        it lies in (lane = (y % 8) * 8 + x % 8) and marks the places of pixels without one: the
+                                        voting shadow walk of the SPECULATIVE build takes one tile per wavefront */
     const PtVertexAux* aux;
     const PtLight* lights;
     const uint16_t* blueNoise;
@@ -250,7 +253,15 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
     } else if (live && wantShadow) {
         f.jobs[j] = nextJob;
     }
-    if (wantShadow) {
+    if (f.tileShadow) {
+        /* the job list is still in pixel order here (depth 0, right after the launch pass): job j is pixel j */
+        if (j < f.W * f.H) {
+            const uint32_t x = j % f.W, y = j / f.W;
+            PtShadowRay* dst = f.shadowRays + ((size_t)(y >> 3) * (f.W >> 3) + (x >> 3)) * 64u + ((y & 7u) << 3) + (x & 7u);
+            if (wantShadow) { const uint4* src = (const uint4*)&sr; uint4* d4 = (uint4*)dst; d4[0] = src[0]; d4[1] = src[1]; d4[2] = src[2]; }
+            else dst->slot = PT_JOB_DEAD;
+        }
+    } else if (wantShadow) {
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
         const uint4* src = (const uint4*)&sr;
         uint4* dst = (uint4*)(f.shadowRays + shBase[1] + shCount[1][wave] + rank);

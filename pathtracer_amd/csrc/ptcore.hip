@@ -734,7 +734,7 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
         HIPCHK(hipMemsetAsync(shadowCtr, 0, 2 * 4, p.stream));
     }   /* overlapped: k_launch cleared every counter, k_record_counts clears the first three after each depth */
     FrameArgs f; fill_frame_args(ctx, p, f, depth);
-    f.shadowRays = p.dShadow[q]; f.fuseCompact = overlapped ? 1u : 0u;
+    f.shadowRays = p.dShadow[q]; f.fuseCompact = overlapped ? 1u : 0u; f.tileShadow = speculative ? 1u : 0u;
     TraceArgs a; fill_trace_args(ctx, a);
     a.stack = p.dStack; a.hitRecs = p.dHitRecs;
     a.jobs = f.jobs; a.countPtr = p.dCtr + CTR_NJOBS; a.fetchCounter = p.dCtr + CTR_FETCH_CLOSEST;
@@ -765,14 +765,24 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
     TraceArgs s; fill_trace_args(ctx, s);
     s.stack = p.dStack; s.shadowRays = p.dShadow[q];
     s.countPtr = shadowCtr; s.fetchCounter = shadowCtr + 1;
+    /* the SPECULATIVE build votes in its shadow walk too (the whole of trace.comp is compiled with it): one wavefront per
+       8x8 tile over the tile-ordered queue the shade pass wrote */
+    auto shadow_pass = [&](hipStream_t st, int area) -> int {
+        if (speculative) {
+            hipLaunchKernelGGL(k_trace_ref_speculative_shadow, dim3(ctx->W / 8, ctx->H / 8), dim3(64), 0, st, s, ctx->W, ctx->H);
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+        return launch_trace<MODE_SHADOW, true>(ctx, s, false, st, area);
+    };
     if (overlapped && ctx->optShadowStream) {
         HIPCHK(hipEventRecord(p.evShade[q], p.stream));
         HIPCHK(hipStreamWaitEvent(p.stream2, p.evShade[q], 0));
-        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, p.stream2, 2 * p.index + 1)) return rc;
+        if (int rc = shadow_pass(p.stream2, 2 * p.index + 1)) return rc;
         HIPCHK(hipEventRecord(p.evShadow[q], p.stream2));
         p.shadowBusy[q] = true;
     } else {
-        if (int rc = launch_trace<MODE_SHADOW, true>(ctx, s, false, p.stream, 2 * p.index)) return rc;
+        if (int rc = shadow_pass(p.stream, 2 * p.index)) return rc;
     }
     return 0;
 }

@@ -331,6 +331,44 @@ __global__ __launch_bounds__(64) void k_trace_ref_speculative(TraceArgs a, uint3
     store_result<MODE_JOBS>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, ranOff ? hitIndex : 0u);
 }
 
+/* The any-hit walk shadeHit makes (trace.comp:123) in the SPECULATIVE build: the same vote, among the lanes of the 8x8
+ * tile whose closest-hit walk found something (the others have returned, trace.comp:194-195).  One wavefront per tile,
+ * shadow rays at queue place tile * 64 + lane (k_shade with tileShadow), places without a ray marked PT_JOB_DEAD.  A
+ * lane that finds an occluder clears its light sample and leaves: it votes no more (stopIfHit, intersections.glsl:97). */
+__global__ __launch_bounds__(64) void k_trace_ref_speculative_shadow(TraceArgs a, uint32_t W, uint32_t H)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint64_t id = ((uint64_t)blockIdx.y * (W >> 3) + blockIdx.x) * 64u + lane;
+    if (a.shadowRays[id].slot == PT_JOB_DEAD) return;
+    RayRegs r; uint32_t exclude = 0, tag = 0;
+    load_ray<MODE_SHADOW>(a, id, r, exclude, tag);
+    uint32_t index = 0;
+    while (index < a.numNodes) {
+        const float4* np = (const float4*)(a.nodes + index);
+        float4 na = np[0], nb = np[1];
+        bool pass = box_raw(r, na, nb);
+        if (__any(pass)) {
+            int32_t right = __float_as_int(nb.w);
+            if (right <= 0 && (exclude == 0 || exclude != index)) {
+                uint32_t tri = (uint32_t)(-right) / 3u;
+                uint32_t v1 = a.indices[3 * tri], v2 = a.indices[3 * tri + 1], v3 = a.indices[3 * tri + 2];
+                float4 p1 = a.positions[v1], p2 = a.positions[v2], p3 = a.positions[v3];
+                float t, al, be, ga;
+                F3 P1 = { p1.x, p1.y, p1.z };
+                if (tri_test(r, P1, fsub({ p2.x, p2.y, p2.z }, P1), fsub({ p3.x, p3.y, p3.z }, P1), t, al, be, ga)) {
+                    store_result<MODE_SHADOW>(a, id, tag, true, t, -1, -1, -1, 0, 0, 0, 0);
+                    return;
+                }
+            }
+            index++;
+        } else {
+            index = (uint32_t)__float_as_int(na.w);
+            if (index == 0) break;
+        }
+    }
+    (void)H;
+}
+
 /* The reference-order walk with one WAVEFRONT per ray, for the few rays the certified walk hands back: a list that short
  * is all latency (the walk of its longest ray, one dependent fetch per node), so the 64 lanes work on one ray instead.
  * The reference's array is in pre-order with skip links, so wherever the walk stands, the nodes it can visit next are the

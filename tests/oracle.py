@@ -23,6 +23,7 @@ assert NODE_DT.itemsize == 32 and SLOT_DT.itemsize == 48 and CONST_DT.itemsize =
 FLAG_REJECT_NAN = 1
 FLAG_SKIP_ODD_INTERIOR = 2      # analysis only (scripts/exp_wide_nodes.py)
 MODE_ZERO_NEXT_SLOT, MODE_RESEED_EVERY_FRAME, MODE_KILL_ON_MISS = 1, 2, 4
+MODE_PLAIN_SHADOW_WALK = 8       # analysis only: the SPECULATIVE build without the vote in its shadow walk
 
 _lib = None
 

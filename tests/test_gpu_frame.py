@@ -106,15 +106,24 @@ def test_dispatch_sites_one_by_one(gpu_ctx, oracle_lib, monkey):
 
 
 def test_speculative_depth0_matches_subgroup64(gpu_ctx, oracle_lib, monkey):
-    """The SPECULATIVE build (subgroup vote) at depth 0 with 64-lane subgroups on 8x8 tiles."""
+    """The SPECULATIVE build (subgroup vote) at depth 0 with 64-lane subgroups on 8x8 tiles: the vote governs the
+    closest-hit walk and the shadow walk shadeHit makes (the whole of trace.comp is compiled with it,
+    CMakeLists.txt:33-36; intersections.glsl:73-77 via trace.comp:123), among the lanes whose closest-hit walk hit.
+    That the shadow walk's vote matters on this scene is checked against an oracle run without it."""
     W, H, NR = 128, 72, 3
     osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    plain = oracle.Frame(W, H, NR)
+    mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS
     for frame in (1, 2):
         c = _consts(monkey, W, H, NR, frame, {})
         gpu_ctx.set_constants(c)
         gpu_ctx.render_sample(frame, speculative_depth0=True)
-        oracle.render_frame(osc, fr, c, subgroup0=64, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+        oracle.render_frame(osc, fr, c, subgroup0=64, mode=mode)
+        oracle.render_frame(osc, plain, c, subgroup0=64, mode=mode | oracle.MODE_PLAIN_SHADOW_WALK)
         _compare(gpu_ctx, fr)
+    differ = int((fr.accumulation != plain.accumulation).any(axis=2).sum())
+    print(f"the vote in the shadow walk changes {differ} of {W * H} pixels")
+    assert differ > 0
 
 
 def test_stale_slot_and_reseed_options(gpu_ctx, oracle_lib, monkey):
