@@ -45,6 +45,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+SAN_MIGUEL_OID = "db0ad4bbfa207d97d1a8aed92dc798078afaf846fc9ac2538567294ac905c139"      # reference Models/SanMiguel.ply:2
+
+
+def sha256_of(path):
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
 
 
 def log(*a):
@@ -59,6 +69,7 @@ def main():
     ap.add_argument("--tris", type=int, default=5_800_000)
     ap.add_argument("--rays", type=int, default=1 << 26)
     ap.add_argument("--traversal", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--scene", type=str, default="", help="a real SanMiguel.ply; accepted only if its sha256 is the oid of the reference's Git-LFS stub")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -87,7 +98,17 @@ def main():
 
     threads = max(1, min(16, (os.cpu_count() or 16) // max(1, world)))
     t0 = time.time()
-    pos, aux, idx = pt.scenes.san_miguel_like(args.tris)
+    scene_name = None
+    if args.scene:
+        # the reference's Models/SanMiguel.ply is a Git-LFS pointer whose second line names the real file's sha256
+        digest = sha256_of(args.scene)
+        if digest == SAN_MIGUEL_OID:
+            pos, aux, idx = pt.load_ply(args.scene)
+            scene_name = f"SanMiguel.ply (the reference's own file, sha256 {digest[:16]}...)"
+        elif rank == 0:
+            log(f"--scene {args.scene}: sha256 {digest} is not the oid of the reference's SanMiguel.ply stub ({SAN_MIGUEL_OID}); using the stand-in")
+    if scene_name is None:
+        pos, aux, idx = pt.scenes.san_miguel_like(args.tris)
     t1 = time.time()
     nodes, ridx, depth = pt.build_bvh(pos, idx, threads)
     t2 = time.time()
@@ -181,8 +202,9 @@ def main():
         "dtype": "f16 box test + f32 triangle test",
         "data": "synthetic",
         "config": {
-            "workload": f"SanMiguel 64M random incoherent closest-hit rays (BASELINE configs[4]); scene = procedural stand-in "
-                        f"san_miguel_like, {ridx.shape[0]} triangles (SanMiguel.ply is a Git-LFS stub in the reference)",
+            "workload": "SanMiguel 64M random incoherent closest-hit rays (BASELINE configs[4]); scene = " +
+                        (f"{scene_name}, {ridx.shape[0]} triangles" if scene_name else
+                         f"procedural stand-in san_miguel_like, {ridx.shape[0]} triangles (SanMiguel.ply is a Git-LFS stub in the reference)"),
             "rays_per_gpu": n,
             "triangles": int(ridx.shape[0]),
             "bvh_nodes": int(nodes.shape[0]),
@@ -238,7 +260,7 @@ def main():
             spos, saux, sidx = pt.scenes.sponza_like()
             snodes, sridx, _ = pt.build_bvh(spos, sidx, threads)
             ctx.upload_scene(spos, saux, sridx, snodes, pt.default_lights(), pt.load_blue_noise())
-            result["extra"]["sponza_stand_in"] = path_tracer_spp(ctx, sridx.shape[0], snodes.shape[0])
+            result["extra"]["sponza_stand_in"] = path_tracer_spp(ctx, sridx.shape[0], snodes.shape[0], camera=pt.scenes.SPONZA_CAMERA)
         except Exception as e:      # the context lines must not take the headline down
             result["extra"] = {"error": str(e)}
     if world > 1 and not args.no_extra:
@@ -275,9 +297,26 @@ def cpu_baseline(pos, aux, ridx, nodes, d_rays, budget_s):
         osc.trace(rays, threads=cores)
         times.append(time.perf_counter() - t)
     med = float(np.median(times))
-    return {"value": round(nsample / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"first {nsample} rays of rank 0's ray set, same scene, 3 repeats, median; reference-faithful CPU walk "
-                      f"(clang++ -O3, {cores} threads)"}
+    out = {"value": round(nsample / med / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "sample": f"first {nsample} rays of rank 0's ray set, same scene, 3 repeats, median; reference-faithful CPU walk "
+                     f"(clang++ -O3, {cores} threads)"}
+    # spp/s of the whole frame graph (launch, 8 x {trace + shade + shadow walk, raysort}, composite) on the same scene and
+    # camera as the GPU's 1080p context line, at a size the CPU serves in seconds; a sample costs the same per pixel
+    # at any size, so the 1080p figure is this one scaled by the pixel count
+    W, H, NR = 480, 270, 8
+    fr = oracle.Frame(W, H, NR)
+    osc2 = oracle.Scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
+    consts = pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **pt.scenes.COURTYARD_CAMERA)
+    mode = oracle.MODE_ZERO_NEXT_SLOT          # missed rays stay in the job list and are traced again each bounce, as in the reference
+    frames, t = 0, time.perf_counter()
+    while frames < 2 or (time.perf_counter() - t < 0.5 * budget_s and frames < 64):
+        consts["frameIndex"] = frames + 1
+        oracle.render_frame(osc2, fr, consts, mode=mode, threads=cores)
+        frames += 1
+    dt = time.perf_counter() - t
+    out["spp_per_s"] = {"value_at_480x270": round(frames / dt, 3), "scaled_to_1080p": round(frames / dt * (W * H) / (1920 * 1080), 4),
+                        "sample": f"{frames} frames of {W}x{H} x {NR} bounces + shadow rays, reference-faithful frame graph, trace passes on {cores} threads"}
+    return out
 
 
 def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
@@ -351,14 +390,14 @@ def certified_frames(ctx, num_triangles, num_nodes):
             "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
 
 
-def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=30):
+def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=30, camera=None):
     """Context number: samples per pixel per second of the wavefront path tracer at 1080p (or the size given), 8 bounces
     with next-event estimation, on the scene the context holds (BASELINE configs[2] shape); frames in flight at the
     library default."""
     import pathtracer_amd as pt
     NR = 8
     ctx.resize(W, H, NR)
-    ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
+    ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **(camera or pt.scenes.COURTYARD_CAMERA)))
     ctx.render_samples(1, 3)
     ctx.synchronize()
     t = time.perf_counter()
@@ -408,17 +447,77 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         return {"error": err or "another rank failed while rendering"}
+    # the library's own RCCL entry points (what a C++ host without torch calls) on the same buffer first: the sum is taken,
+    # read back and the buffer restored, then torch's all-reduce runs on it and the two results are compared
+    native = native_allreduce_check(ctx, rank, world, backend, dev)
+    t_ar = time.perf_counter()
     distributed.allreduce_accumulation_torch(ctx)       # raises on every rank or on none: same library, same buffer size
-    dt = time.perf_counter() - t
+    dt = time.perf_counter() - t - native["seconds_spent"]
+    t_torch = time.perf_counter() - t_ar
     tt = torch.tensor([dt, t_render], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, t_render = float(tt[0].item()), float(tt[1].item())
     out = {f"spp_per_s_{H}p": round(world * nf / dt, 2), "frames_per_rank": nf, "bounces": NR, "triangles": int(num_triangles),
            "render_s": round(t_render, 4), "allreduce_s": round(dt - t_render, 4), "allreduce_bytes": 16 * W * H}
+    acc = ctx.readback_accumulation()
+    if native.get("result") is not None:
+        same = np.array_equal(native["result"][..., 3], acc[..., 3]) and np.allclose(native["result"], acc, rtol=1e-6, atol=1e-7)
+        native["equals_torch_allreduce"] = bool(same)
+        native["max_abs_difference"] = float(np.abs(native["result"] - acc).max())
+        native["torch_allreduce_s"] = round(t_torch, 4)
+        agree = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        native["equals_torch_allreduce_on_every_rank"] = bool(int(agree.item()))
+    native.pop("result", None); native.pop("seconds_spent", None)
+    out["native_rccl_entry_points"] = native
     if rank == 0:
-        acc = ctx.readback_accumulation()
         out["samples_per_pixel_after_allreduce"] = [float(acc[..., 3].min()), float(acc[..., 3].max())]
     ctx.set_option(core.OPT_RESEED, 0)
+    return out
+
+
+def native_allreduce_check(ctx, rank, world, backend, dev):
+    """pt_comm_unique_id / pt_comm_init / pt_allreduce_accumulation with N > 1: rank 0's id goes to every rank over the
+    torch group, every rank joins the communicator and sums its accumulation in place; the sum is read back and the
+    buffer put back as it was, so that the torch all-reduce that follows starts from the same data.  Every rank enters
+    every collective: a rank that fails locally says so in a flag that is reduced before the next one.  Skipped where
+    ranks share a device (the gloo rehearsal), which RCCL refuses."""
+    import torch
+    import torch.distributed as dist
+    from pathtracer_amd import core
+    t0 = time.perf_counter()
+    if backend != "nccl":
+        return {"skipped": "ranks share a device in this rehearsal", "result": None, "seconds_spent": time.perf_counter() - t0}
+    out = {"result": None}
+    try:
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        ok = 1
+        if rank == 0:
+            try:
+                uid = torch.from_numpy(core.comm_unique_id().copy()).to(dev)
+            except Exception as e:
+                ok, out["error"] = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, 0)
+        if int(flag.item()) == 0:
+            out.setdefault("error", "rank 0 could not make a communicator id")
+            out["seconds_spent"] = time.perf_counter() - t0
+            return out
+        dist.broadcast(uid, 0)
+        before = ctx.readback_accumulation()
+        ctx.comm_init(rank, world, uid.cpu().numpy())            # collective: every rank is here
+        ctx.synchronize()
+        dist.barrier()
+        t = time.perf_counter()
+        ctx.allreduce_accumulation()
+        ctx.synchronize()
+        out["allreduce_s"] = round(time.perf_counter() - t, 4)
+        out["result"] = ctx.readback_accumulation()
+        ctx.upload_accumulation(before)
+    except Exception as e:
+        out["error"] = str(e)
+        out["result"] = None
+    out["seconds_spent"] = time.perf_counter() - t0
     return out
 
 

@@ -548,7 +548,8 @@ struct PoFrame {
     std::vector<uint32_t> jobs;
     std::vector<float> accumulation;     /* RGBA32F */
     std::vector<uint16_t> current;       /* RGBA16F */
-    uint64_t closestRays = 0, shadowRays = 0;
+    std::atomic<uint64_t> closestRays{0}, shadowRays{0};     /* atomic: po_render_frame_mt walks tile rows on several threads */
+    int traceThreads = 1;                                    /* set by po_render_frame_mt for the duration of a frame */
     TraceCounters counters;
 };
 
@@ -782,11 +783,12 @@ static void beginJob(const PoFrame& f, uint32_t jobIndex, TraceJobState& j)     
 /* trace.comp:237-258 over the whole job grid.  subgroup = 0: plain build.  subgroup > 0: the
  * SPECULATIVE build with subgroups of that many lanes; lane k of an 8x8 workgroup handles tile
  * position (k % 8, k / 8) and a subgroup is `subgroup` consecutive lanes. */
-PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, int subgroup, int mode, int flags)
+static void trace_tile_rows(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, int subgroup, int mode, int flags,
+                            uint32_t tyBegin, uint32_t tyEnd, TraceCounters* counters)
 {
     const uint32_t W = (uint32_t)c->viewportSize[0], H = (uint32_t)c->viewportSize[1];
     std::vector<TraceJobState> js(64);
-    for (uint32_t ty = 0; ty < (H + 7) / 8; ty++)
+    for (uint32_t ty = tyBegin; ty < tyEnd; ty++)
         for (uint32_t tx = 0; tx < (W + 7) / 8; tx++) {
             int nj = 0;
             for (uint32_t k = 0; k < 64; k++) {
@@ -801,11 +803,11 @@ PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, 
                 for (uint32_t k = 0; k < 64; k++) {
                     if (!js[k].live) continue;
                     f->closestRays++;
-                    js[k].hit = traceRayFast(*sc, js[k].r, js[k].isect, false, flags, &f->counters);
+                    js[k].hit = traceRayFast(*sc, js[k].r, js[k].isect, false, flags, counters);
                     if (finishJobBefore(*sc, *f, *c, js[k], mode)) {
                         Intersection isectDL{};
                         Ray rl = js[k].shade.rLight;
-                        bool occluded = traceRayFast(*sc, rl, isectDL, true, flags, &f->counters);            /* trace.comp:123 */
+                        bool occluded = traceRayFast(*sc, rl, isectDL, true, flags, counters);            /* trace.comp:123 */
                         finishJobAfter(*f, *c, js[k], occluded, mode);
                     }
                 }
@@ -817,7 +819,7 @@ PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, 
                     if (rr.empty()) continue;
                     std::vector<char> hv(rr.size());
                     f->closestRays += rr.size();
-                    traceRayGroup(*sc, rr.data(), ii.data(), hv.data(), (int)rr.size(), false, true, flags, &f->counters);
+                    traceRayGroup(*sc, rr.data(), ii.data(), hv.data(), (int)rr.size(), false, true, flags, counters);
                     for (size_t q = 0; q < rr.size(); q++) { js[who[q]].r = rr[q]; js[who[q]].isect = ii[q]; js[who[q]].hit = hv[q] != 0; }
                     /* The whole of trace.comp is compiled with SPECULATIVE (CMakeLists.txt:33-36), so the vote of
                        intersections.glsl:73-77 also governs the any-hit walk shadeHit makes (trace.comp:123).  Its
@@ -828,12 +830,27 @@ PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, 
                         if (finishJobBefore(*sc, *f, *c, js[who[q]], mode)) { sr.push_back(js[who[q]].shade.rLight); si.push_back(Intersection{}); sw.push_back(who[q]); }
                     if (!sr.empty()) {
                         std::vector<char> occ(sr.size());
-                        traceRayGroup(*sc, sr.data(), si.data(), occ.data(), (int)sr.size(), true, !(mode & PO_MODE_PLAIN_SHADOW_WALK), flags, &f->counters);
+                        traceRayGroup(*sc, sr.data(), si.data(), occ.data(), (int)sr.size(), true, !(mode & PO_MODE_PLAIN_SHADOW_WALK), flags, counters);
                         for (size_t q = 0; q < sr.size(); q++) finishJobAfter(*f, *c, js[sw[q]], occ[q] != 0, mode);
                     }
                 }
             }
         }
+}
+
+/* A job reads and writes its own pixel's slots and its own job entry only, so tile rows can be walked side by side:
+ * with f->traceThreads > 1 (po_render_frame_mt, the timed CPU baseline) they are, without the visit statistics. */
+PO_API void po_trace(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, int subgroup, int mode, int flags)
+{
+    const uint32_t H = (uint32_t)c->viewportSize[1], rows = (H + 7) / 8;
+    int nt = f->traceThreads;
+    if (nt <= 1 || rows < 2) { trace_tile_rows(sc, f, c, subgroup, mode, flags, 0, rows, &f->counters); return; }
+    if ((uint32_t)nt > rows) nt = (int)rows;
+    std::atomic<uint32_t> next{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&]() { for (uint32_t r = next.fetch_add(1); r < rows; r = next.fetch_add(1)) trace_tile_rows(sc, f, c, subgroup, mode, flags, r, r + 1, nullptr); });
+    for (auto& t : th) t.join();
 }
 
 /* raysort.comp:23-55: per (row, 256-wide segment) the live jobs move to the front of the segment.
@@ -899,6 +916,16 @@ PO_API void po_render_frame(const PoScene* sc, PoFrame* f, const PtShaderConstan
         if (ray_sort && d != c->numRays - 1) po_raysort(f, c);
     }
     po_composite(f, c);
+}
+
+/* The same frame with the trace passes on num_threads threads (tile rows dealt dynamically); every buffer comes out as
+ * po_render_frame leaves it, only the box/triangle test statistics are not kept.  For the timed CPU baseline. */
+PO_API void po_render_frame_mt(const PoScene* sc, PoFrame* f, const PtShaderConstants* c, int subgroup0, int ray_sort, int mode, int flags, int num_threads)
+{
+    if (num_threads <= 0) num_threads = (int)std::thread::hardware_concurrency();
+    f->traceThreads = num_threads < 1 ? 1 : num_threads;
+    po_render_frame(sc, f, c, subgroup0, ray_sort, mode, flags);
+    f->traceThreads = 1;
 }
 
 /* Exposes single operations for unit tests of the fp16 helpers. */

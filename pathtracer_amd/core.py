@@ -393,6 +393,12 @@ class PathTracer:
         self._chk(self._L.pt_readback_accumulation(self._h, _p(out)))
         return out
 
+    def upload_accumulation(self, acc):
+        """Overwrites the RGBA32F accumulation with a host image (H, W, 4) float32."""
+        acc = np.ascontiguousarray(acc, dtype=np.float32)
+        assert acc.shape == (self.H, self.W, 4)
+        self._chk(self._L.pt_copy_to_device(self._h, self.accumulation_device_ptr(), _p(acc), acc.nbytes))
+
     def readback_current(self):
         out = np.zeros((self.H, self.W, 4), dtype=np.uint16)
         self._chk(self._L.pt_readback_current(self._h, _p(out)))

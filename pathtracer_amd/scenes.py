@@ -232,8 +232,71 @@ COURTYARD_CAMERA = dict(orbit_angle=2.4, orbit_radius=2.6, orbit_height=1.4, foc
 
 
 def sponza_like(num_triangles=262_144, seed=11):
-    """Stand-in for sponza.ply (a 16.8 MB PLY whose geometry is not in the reference checkout)."""
-    return courtyard(num_triangles, seed=seed, extent=2.0)
+    """Stand-in for sponza.ply (a 16.8 MB PLY whose geometry is not in the reference checkout): an atrium of the
+    Sponza kind, different in character from the courtyard stand-in - a long nave between two-storey colonnades, the
+    nave open to the sky, a few large occluders (walls, gallery slabs, columns) and rows of draped cloth
+    that carry a third of the triangles; no foliage soup.  Spans [-2,2] x [0,1.7] x [-0.9,0.9]."""
+    rng = np.random.default_rng(seed)
+    m = _Mesh()
+    budget = int(num_triangles)
+    stone, plaster, floor_c = (200, 190, 170, 255), (225, 218, 200, 255), (150, 140, 125, 255)
+    cloths = [(170, 40, 40, 255), (40, 70, 150, 255), (50, 130, 60, 255), (190, 160, 60, 255)]
+    LX, HY, HZ = 2.0, 1.7, 0.9
+
+    # floor: worn paving, ~14 %
+    g = max(2, int(np.sqrt(0.14 * budget / 2 / 2.2)))
+    fx, fz = rng.random(3) * 7 + 2, rng.random(3) * 7 + 2
+    _quad(m, (-LX, 0, -HZ), (0, 0, 2 * HZ), (2 * LX, 0, 0), g, int(2.2 * g), floor_c,
+          height=lambda s_, t_: 0.003 * sum(np.sin(fx[k] * s_ * 6.28) * np.cos(fz[k] * t_ * 6.28) for k in range(3)))
+    # long walls, end walls, and eaves over the galleries: the nave is open to the sky, ~12 %
+    w = max(1, int(np.sqrt(0.12 * budget / 2 / 12)))
+    _quad(m, (-LX, 0, -HZ), (2 * LX, 0, 0), (0, HY, 0), 4 * w, w, plaster)                  # z = -HZ, normal +z
+    _quad(m, (LX, 0, HZ), (-2 * LX, 0, 0), (0, HY, 0), 4 * w, w, plaster)                   # z = +HZ, normal -z
+    _quad(m, (-LX, 0, HZ), (0, 0, -2 * HZ), (0, HY, 0), 2 * w, w, plaster)                  # x = -LX, normal +x
+    _quad(m, (LX, 0, -HZ), (0, 0, 2 * HZ), (0, HY, 0), 2 * w, w, plaster)                   # x = +LX, normal -x
+    _quad(m, (-LX, HY, -HZ), (2 * LX, 0, 0), (0, 0, 0.30 * HZ), 2 * w, max(1, w // 3), plaster)     # eaves over the -z gallery (normal -y)
+    _quad(m, (LX, HY, HZ), (-2 * LX, 0, 0), (0, 0, -0.30 * HZ), 2 * w, max(1, w // 3), plaster)     # eaves over the +z gallery
+
+    # colonnades: two rows of columns on two storeys, lintels and gallery slabs, ~26 %
+    ncol = 14
+    seg = int(min(2048, max(8, 0.26 * budget * 0.8 / (4 * ncol * 2))))
+    xs = np.linspace(-0.9 * LX, 0.9 * LX, ncol)
+    for zrow in (-0.52 * HZ, 0.52 * HZ):
+        for y0, hgt, rad in ((0.0, 0.72, 0.045), (0.80, 0.62, 0.035)):
+            base = np.stack([xs, np.full_like(xs, y0), np.full_like(xs, zrow)], 1)
+            _cylinders(m, base, rad, hgt, seg, stone)
+            _boxes(m, base + np.array([0, hgt + 0.02, 0]), (0.07, 0.02, 0.07), stone)       # capitals
+        sign = 1.0 if zrow > 0 else -1.0
+        _boxes(m, [(0.0, 0.77, zrow + sign * 0.24 * HZ)], [(LX, 0.03, 0.24 * HZ + 0.05)], plaster)  # gallery floor slab
+        _boxes(m, [(0.0, 0.745, zrow)], [(LX, 0.025, 0.05)], stone)                          # lintel over the ground-floor columns
+        _boxes(m, [(0.0, 1.465, zrow)], [(LX, 0.025, 0.05)], stone)                          # and over the gallery's
+
+    # vases along the nave, ~4 %
+    nv = 8
+    lat = max(6, int(np.sqrt(0.04 * budget / nv / 2)))
+    vc = np.stack([np.linspace(-0.8 * LX, 0.8 * LX, nv), np.full(nv, 0.09), np.where(np.arange(nv) % 2 == 0, -0.25, 0.25) * HZ], 1)
+    _spheres(m, vc, 0.09, lat, lat, stone)
+
+    # draped cloth: hanging banners across the nave and curtains between gallery columns; they take what is left
+    left = budget - m.num_triangles()
+    nb = 10
+    bays = [(zrow, k) for zrow in (-0.52 * HZ, 0.52 * HZ) for k in range(ncol - 1) if (k + (zrow > 0)) % 3 != 0]   # every third bay stays open
+    per = max(8, left // (nb + len(bays)))                                   # triangles per piece of cloth
+    bu = max(2, int(round(np.sqrt(per / 2 / 1.6)))); bv = max(2, int(round(per / 2 / bu)))
+    for k, x in enumerate(np.linspace(-0.7 * LX, 0.55 * LX, nb)):
+        ph = rng.random(3) * 6.28
+        _quad(m, (x, 1.50, -0.30 * HZ), (0, 0, 0.60 * HZ), (0, -0.55, 0), bu, bv, cloths[k % 4],
+              height=lambda s_, t_, ph=ph: 0.035 * np.sin(5.0 * s_ * 6.28 + ph[0]) * (0.3 + t_) + 0.02 * np.sin(2.0 * t_ * 6.28 + ph[1]))
+    cu = max(2, int(round(np.sqrt(per / 2)))); cv = max(2, int(round(per / 2 / cu)))
+    for zrow, k in bays:
+        ph = rng.random(2) * 6.28
+        _quad(m, (xs[k] + 0.04, 1.40, zrow), (xs[k + 1] - xs[k] - 0.08, 0, 0), (0, -0.52, 0), cu, cv, cloths[(k + 1) % 4],
+              height=lambda s_, t_, ph=ph: 0.03 * np.sin(4.0 * s_ * 6.28 + ph[0]) * (0.2 + t_) + 0.015 * np.sin(3.0 * t_ * 6.28 + ph[1]))
+    return m.finish()
+
+
+# A camera for the atrium stand-in: at one end of the nave, a little above head height, looking down its length.
+SPONZA_CAMERA = dict(orbit_angle=0.0, orbit_radius=1.75, orbit_height=0.15, focus_center=(0.0, 0.55, 0.0))
 
 
 def san_miguel_like(num_triangles=5_800_000, seed=13):

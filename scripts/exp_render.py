@@ -26,7 +26,7 @@ elif args.scene == "sanmiguel":
     cam = dict(pt.scenes.COURTYARD_CAMERA)
 else:
     pos, aux, idx = pt.scenes.sponza_like()
-    cam = dict(pt.scenes.COURTYARD_CAMERA)
+    cam = dict(pt.scenes.SPONZA_CAMERA)
 nodes, ridx, _ = pt.build_bvh(pos, idx, 16)
 ctx = pt.PathTracer(0)
 ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())

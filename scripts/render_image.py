@@ -27,7 +27,7 @@ elif args.scene == "sanmiguel":
     cam = dict(pt.scenes.COURTYARD_CAMERA)
 else:
     pos, aux, idx = pt.scenes.sponza_like()
-    cam = dict(pt.scenes.COURTYARD_CAMERA)
+    cam = dict(pt.scenes.SPONZA_CAMERA)
 if args.angle is not None: cam["orbit_angle"] = args.angle
 if args.radius is not None: cam["orbit_radius"] = args.radius
 if args.cheight is not None: cam["orbit_height"] = args.cheight

@@ -54,6 +54,7 @@ def lib():
         L.po_composite.argtypes = [vp, vp]
         L.po_tonemap.argtypes = [vp, C.c_uint64, vp]
         L.po_render_frame.argtypes = [vp, vp, vp, i32, i32, i32, i32]
+        L.po_render_frame_mt.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32]
         L.po_intersect_bbox.argtypes = [vp, vp, vp]
         L.po_intersect_bbox.restype = i32
         L.po_weyl.argtypes = [u32, vp]
@@ -185,5 +186,8 @@ def tonemap(accumulation):
     return out
 
 
-def render_frame(scene, frame, consts, subgroup0=0, ray_sort=True, mode=MODE_ZERO_NEXT_SLOT, flags=FLAG_REJECT_NAN):
-    lib().po_render_frame(scene.h, frame.h, _p(consts), subgroup0, int(ray_sort), mode, flags)
+def render_frame(scene, frame, consts, subgroup0=0, ray_sort=True, mode=MODE_ZERO_NEXT_SLOT, flags=FLAG_REJECT_NAN, threads=1):
+    if threads == 1:
+        lib().po_render_frame(scene.h, frame.h, _p(consts), subgroup0, int(ray_sort), mode, flags)
+    else:
+        lib().po_render_frame_mt(scene.h, frame.h, _p(consts), subgroup0, int(ray_sort), mode, flags, threads)

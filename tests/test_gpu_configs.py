@@ -24,6 +24,7 @@ from test_gpu_frame import _compare, _consts
 pytestmark = pytest.mark.gpu
 
 CAM = pt.scenes.COURTYARD_CAMERA
+SPONZA_CAM = pt.scenes.SPONZA_CAMERA
 
 
 def _model(pos, aux, idx, threads=16):
@@ -48,12 +49,12 @@ def ctx():
     c.close()
 
 
-def _prepare(ctx, model, W, H, NR, trav, reseed=0, in_flight=3):
+def _prepare(ctx, model, W, H, NR, trav, reseed=0, in_flight=3, cam=CAM):
     helpers.upload(ctx, model, pt.default_lights(), pt.load_blue_noise())
     ctx.resize(W, H, NR)
     for o, v in ((core.OPT_TRAVERSAL, trav), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, reseed), (core.OPT_FRAMES_IN_FLIGHT, in_flight)):
         ctx.set_option(o, v)
-    ctx.set_constants(_consts(model, W, H, NR, 1, CAM))
+    ctx.set_constants(_consts(model, W, H, NR, 1, cam))
 
 
 def _check_counts(rc, NR, W, H, frames=1):
@@ -75,11 +76,11 @@ def test_sponza_8_bounces_nee_oracle_parity(ctx, oracle_lib, sponza, trav):
     """Every byte of the ray stack, the current image and the accumulation equals the oracle's after each of two
     frames of 8 bounces with shadow rays on the 262 k-triangle sponza stand-in."""
     W, H, NR = 256, 144, 8
-    _prepare(ctx, sponza, W, H, NR, trav, in_flight=1)
+    _prepare(ctx, sponza, W, H, NR, trav, in_flight=1, cam=SPONZA_CAM)
     osc = helpers.oracle_scene(sponza, pt.default_lights(), pt.load_blue_noise())
     fr = oracle.Frame(W, H, NR)
     for frame in (1, 2):
-        c = _consts(sponza, W, H, NR, frame, CAM)
+        c = _consts(sponza, W, H, NR, frame, SPONZA_CAM)
         ctx.set_constants(c)
         rc = ctx.render_sample(frame, want_ray_counts=True)
         before = fr.ray_counts().copy()
@@ -97,7 +98,7 @@ def test_sponza_1080p_8_bounces_properties(ctx, sponza):
     defaults.  The default (near-child-first) walk by its properties and twice for determinism; the certified walk
     against the reference-order walk byte for byte."""
     W, H, NR, NF = 1920, 1080, 8, 4
-    _prepare(ctx, sponza, W, H, NR, core.TRAVERSAL_FLAT_ORDERED)
+    _prepare(ctx, sponza, W, H, NR, core.TRAVERSAL_FLAT_ORDERED, cam=SPONZA_CAM)
     images = []
     for rep in range(2):
         ctx.clear_accumulation()
@@ -115,9 +116,13 @@ def test_sponza_1080p_8_bounces_properties(ctx, sponza):
         exact[trav] = (ctx.readback_accumulation(), ctx.readback_current())
     a, b = exact[core.TRAVERSAL_FLAT], exact[core.TRAVERSAL_CERTIFIED]
     assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])
-    # the default walk's image is the reference-order image up to the few near-tie rays: within 2 % RMSE of the mean
+    # the default walk's image is the reference-order image up to the few near-tie rays: a pixel differs only where one
+    # of its paths met such a ray (at most 1e-4 of rays do, and a path has up to 8 closest-hit rays per frame), and the
+    # RMSE over the whole image stays within 5 % of the mean radiance at these 4 spp
+    differ = (images[0] != a[0]).any(axis=2).mean()
     rmse = np.sqrt(((images[0] - a[0])[..., :3] ** 2).mean())
-    assert rmse <= 0.02 * a[0][..., :3].mean()
+    print(f"near-first against reference order: {differ:.2e} of pixels differ, RMSE {rmse:.3e} at mean {a[0][..., :3].mean():.3e}")
+    assert differ <= 1e-4 * NR * NF and rmse <= 0.05 * a[0][..., :3].mean()
 
 
 def test_san_miguel_4k_8_bounces_properties(ctx, san_miguel):
