@@ -276,9 +276,15 @@ enum {
     PT_OPT_SECOND_WALK    = 11,  /* how PT_OPT_TRAVERSAL = 3 walks the rays its first pass lists, in reference order: 0 = one
                                     ray per lane (the walk of traversal 1); 1 (default) = one ray per wavefront, 64 nodes of
                                     the reference array fetched and box-tested at a time.  Same hits, bit for bit */
-    PT_OPT_SHADOW_STREAM  = 12,  /* 1 (default): inside pt_render_sample[s] the shadow pass of depth d runs on a second stream
-                                    beside the closest-hit pass of depth d+1; 0: on the frame's own stream, after the shade
-                                    pass (half as many streams: for hosts that are short of hardware queues) */
+    PT_OPT_SHADOW_STREAM  = 12,  /* inside pt_render_sample[s], where a bounce's shadow pass is a launch of its own: 1 = on a
+                                    second stream beside the closest-hit pass of the next bounce; 0 = on the frame's own
+                                    stream, after the shade pass (half as many streams: for hosts short of hardware
+                                    queues); 2 (default) = 1 where the passes cannot be merged (PT_OPT_MERGE_PASSES), else 0 */
+    PT_OPT_MERGE_PASSES   = 13,  /* inside pt_render_sample[s]: 1 (default) = the shadow rays of bounce d are traced by the same
+                                    launch as the closest-hit rays of bounce d + 1 (both wait for the shade pass of d only):
+                                    half the launches, one stream per frame, and a frame rate that no longer hinges on the
+                                    number of hardware queues; needs traversal 1 or 2 on 64 B or 48 B records, otherwise the
+                                    passes stay apart.  Results do not depend on it */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and pair of streams; results do not depend on it.  Three frames are six
                                     streams, and HIP gives a process four hardware queues unless the environment

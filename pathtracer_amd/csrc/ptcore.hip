@@ -117,6 +117,7 @@ struct FramePipe {
     PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow[2] = { nullptr, nullptr };
     uint32_t* dCtr = nullptr; unsigned long long* dRayCounts = nullptr;
     uint32_t* dFlag = nullptr;                            /* certified walk: jobs listed for the second walk (allocated on first use) */
+    int deferredShadow = -1;                              /* bounce whose shadow pass waits to run inside the next bounce's closest-hit launch */
 };
 
 struct PtContext {
@@ -152,7 +153,7 @@ struct PtContext {
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 1;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1;
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
@@ -298,6 +299,29 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
     } else {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_flat<MODE_RAYS, ANYHIT, true, true, false>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_flat<MODE, ANYHIT, true, false, false>), grid, block, 0, stream, a);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* The closest-hit pass of one bounce and the shadow pass of the bounce before it as one launch (MODE_MIXED of k_trace_flat,
+ * 64 B or 48 B records, traversals 1 and 2): both wait for the same shade pass and for nothing else, so one pool of rays keeps
+ * more lanes busy than two launches side by side, and a frame needs one stream instead of two. */
+int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area)
+{
+    if (int rc = ensure_overflow(ctx)) return rc;
+    a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
+    a.overflowEntries = ctx->overflowEntries;
+    /* two passes' rays in one pool: one more workgroup per CU than a pass alone gets (measured: 3, 4, 5 -> 158, 160, 161 spp/s) */
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : 4)), block(PT_BLOCK);
+    a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
+    const bool ordered = ctx->optTraversal != 1;
+    if (ctx->compact) {
+        if (ordered) hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, true, false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, false, false, true>), grid, block, 0, stream, a);
+    } else {
+        if (ordered) hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, true, false, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, false, false, false>), grid, block, 0, stream, a);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -500,7 +524,8 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_RECORD_LAYOUT: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_RECORD_LAYOUT must be 0, 1 or 2"); ctx->optRecordLayout = value; return 0;
         case PT_OPT_SORT_BITS: if (value < 1 || value > 4) return ctx->fail(-1, "PT_OPT_SORT_BITS must be 1..4"); ctx->optSortBits = value; return 0;
         case PT_OPT_SORT_RAYS: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SORT_RAYS must be 0, 1 or 2"); ctx->optSortRays = value; return 0;
-        case PT_OPT_SHADOW_STREAM: ctx->optShadowStream = value != 0; return 0;
+        case PT_OPT_SHADOW_STREAM: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SHADOW_STREAM must be 0, 1 or 2"); ctx->optShadowStream = value; return 0;
+        case PT_OPT_MERGE_PASSES: ctx->optMergePasses = value != 0; return 0;
         case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
@@ -519,6 +544,7 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_FRAMES_IN_FLIGHT: *value = ctx->optFramesInFlight; return 0;
         case PT_OPT_SECOND_WALK: *value = ctx->optSecondWalk; return 0;
         case PT_OPT_SHADOW_STREAM: *value = ctx->optShadowStream; return 0;
+        case PT_OPT_MERGE_PASSES: *value = ctx->optMergePasses; return 0;
         case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
         case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;
         case PT_OPT_RECORD_LAYOUT: *value = ctx->optRecordLayout; return 0;
@@ -695,7 +721,7 @@ static int launch_on(PtContext* ctx, FramePipe& p)
     if (!ctx->dBlueNoise) return ctx->fail(-2, "pt_launch: scene was uploaded without a blue-noise table");
     FramePipe& src = ctx->pipe[ctx->rngPipe];
     if (&src != &p && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(p.stream, src.evShade0, 0));
-    p.curJobs = 0;
+    p.curJobs = 0; p.deferredShadow = -1;
     FrameArgs f; fill_frame_args(ctx, p, f);
     dim3 grid((ctx->W + 31) / 32, (ctx->H + 7) / 8), block(256);
     hipLaunchKernelGGL(k_launch, grid, block, 0, p.stream, f);
@@ -748,9 +774,15 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
         uint32_t* flagCtr = p.dCtr + ctr_flag_base(ctx->slots) + 2 * depth;
         if (!overlapped) HIPCHK(hipMemsetAsync(flagCtr, 0, 2 * 4, p.stream));          /* overlapped: k_launch cleared them */
         if (int rc = launch_cert<MODE_JOBS>(ctx, a, false, p.stream, 2 * p.index, p.dFlag, flagCtr)) return rc;
+    } else if (p.deferredShadow >= 0) {
+        /* the shadow rays the last bounce's shade pass queued ride along */
+        const int d0 = p.deferredShadow;
+        a.shadowRays = p.dShadow[d0 & 1]; a.countPtr2 = p.dCtr + CTR_SHADOW + 2 * d0;
+        if (int rc = launch_mixed(ctx, a, p.stream, 2 * p.index)) return rc;
     } else {
         if (int rc = launch_trace<MODE_JOBS, false>(ctx, a, false, p.stream, 2 * p.index)) return rc;
     }
+    p.deferredShadow = -1;
     if (p.shadowBusy[q]) {         /* the shade pass rewrites queue q: the shadow pass of depth-2 must be through with it */
         HIPCHK(hipStreamWaitEvent(p.stream, p.evShadow[q], 0));
         p.shadowBusy[q] = false;
@@ -775,7 +807,17 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
         }
         return launch_trace<MODE_SHADOW, true>(ctx, s, false, st, area);
     };
-    if (overlapped && ctx->optShadowStream) {
+    /* merged passes: this bounce's shadow rays wait for the next bounce's closest-hit launch, unless there is none, or that
+       launch is one of the kinds that cannot take them (certified walk, treelets, the reference layout) */
+    const bool mergeable = ctx->optMergePasses && (ctx->optTraversal == 1 || ctx->optTraversal == 2) && !ctx->dTreelets;
+    if (overlapped && mergeable && !speculative && depth + 1 < ctx->consts.numRays) {
+        p.deferredShadow = (int)depth;
+        return 0;
+    }
+    /* a side stream pays where the shadow pass is a launch of its own at every bounce; with merged passes only the last
+       bounce's is, and one stream per frame leaves more hardware queues to the other frames in flight */
+    const bool sideStream = ctx->optShadowStream == 2 ? !mergeable : ctx->optShadowStream != 0;
+    if (overlapped && sideStream) {
         hipStream_t side = p.stream2;       /* (one side stream shared by all frames in flight was tried: 94 against 136 spp/s) */
         HIPCHK(hipEventRecord(p.evShade[q], p.stream));
         HIPCHK(hipStreamWaitEvent(side, p.evShade[q], 0));

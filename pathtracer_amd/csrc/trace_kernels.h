@@ -57,7 +57,10 @@ struct PtShadowRay {
     uint32_t _pad[3];
 };
 
-enum { MODE_RAYS = 0, MODE_JOBS = 1, MODE_SHADOW = 2 };
+enum { MODE_RAYS = 0, MODE_JOBS = 1, MODE_SHADOW = 2,
+       MODE_MIXED = 3 };    /* k_trace_flat only: ids below *countPtr are jobs (closest hit), the *countPtr2 ids above them shadow rays
+                               (any hit) - the closest-hit pass of one bounce and the shadow pass of the bounce before it, which
+                               both wait for the same shade pass and for nothing else, as one launch */
 
 struct TraceArgs {
     /* reference layout */
@@ -81,6 +84,7 @@ struct TraceArgs {
     /* work */
     uint32_t*        fetchCounter;   /* next unclaimed ray */
     const uint32_t*  countPtr;       /* number of rays, read on the device (nullptr: use count) */
+    const uint32_t*  countPtr2;      /* MODE_MIXED: number of shadow rays behind the *countPtr jobs */
     uint64_t         count;
     uint32_t         refillMin;      /* refill a wavefront when this many lanes are idle */
     uint32_t         claimChunk;     /* ids a wavefront takes from the counter at a time (0: chosen from the ray count) */
@@ -528,11 +532,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
-    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
+    const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
     bool active = false, pend = false;      /* pend: this lane has fetched the index of its next ray but not the ray */
+    bool shadowLane = MODE == MODE_SHADOW, freshShadow = false;      /* MODE_MIXED: what kind of ray the lane walks / has just loaded */
     uint32_t pendIdx = 0;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;       /* rcpD duplicated into both halves */
@@ -552,8 +558,20 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
 
     /* turns the words a lane loaded into its next ray: root box test, traversal state */
+    /* the three places where a mixed launch has to ask what kind of ray a lane holds */
+    auto issue = [&](uint64_t rid, RayWords& w) -> bool {
+        if (MODE != MODE_MIXED) return issue_ray<MODE>(a, rid, w);
+        freshShadow = rid >= numJobs;
+        return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
+    };
+    auto store = [&](bool h, float t, int32_t s1, int32_t s2, int32_t s3, float al, float be, float ga, uint32_t orig) {
+        if (MODE != MODE_MIXED) store_result<MODE>(a, id, tag, h, t, s1, s2, s3, al, be, ga, orig);
+        else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, t, s1, s2, s3, al, be, ga, orig);
+        else store_result<MODE_JOBS>(a, id, tag, h, t, s1, s2, s3, al, be, ga, orig);
+    };
     auto start_ray = [&](const RayWords& w) {
-        finish_ray<MODE>(w, r, exclude, tag);
+        if (MODE != MODE_MIXED) finish_ray<MODE>(w, r, exclude, tag);
+        else { shadowLane = freshShadow; if (shadowLane) finish_ray<MODE_SHADOW>(w, r, exclude, tag); else finish_ray<MODE_JOBS>(w, r, exclude, tag); }
 #ifdef PT_EXPERIMENT_SAMELINE
         if (COUNT) { nRay++; prevLine = 0xFFFFFFFFu; }
 #else
@@ -566,7 +584,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         float ftmin;
         bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
         if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
-        else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);      /* root box missed */
+        else store(false, r.max_t, -1, -1, -1, 0, 0, 0, 0);      /* root box missed */
     };
 
     for (;;) {
@@ -581,13 +599,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         RayWords w;
         if (MODE != MODE_SHADOW && pend) {      /* the index fetched a turn ago names this lane's next ray */
             id = pendIdx; pend = false;
-            fresh = issue_ray<MODE>(a, id, w);
+            fresh = issue(id, w);
         }
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
             if (canTake && nid != ~0ull) {
                 if (MODE != MODE_SHADOW && a.order) { pendIdx = a.order[nid]; pend = true; }   /* used next turn: no wait here */
-                else { id = nid; fresh = issue_ray<MODE>(a, id, w); }
+                else { id = nid; fresh = issue(id, w); }
             }
         }
 #ifdef PT_SYNC_REFILL
@@ -650,8 +668,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                     r.max_t = t; alpha = al; beta = be; gamma = ga;
                     hit = true;
                     if (MODE != MODE_SHADOW) { hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w; }
-                    if (MODE == MODE_JOBS) hitLeaf = leafId;
-                    if (ANYHIT) { done = true; needPop = false; }
+                    if (MODE == MODE_JOBS || MODE == MODE_MIXED) hitLeaf = leafId;
+                    if (ANYHIT || (MODE == MODE_MIXED && shadowLane)) { done = true; needPop = false; }
                 }
             }
         } else {
@@ -698,8 +716,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
 
         if (done) {
             uint32_t orig = 0u;
-            if (MODE == MODE_JOBS && ranOff && hit) orig = COMPACT ? a.leafRef[hitLeaf & ~PT_LEAF_BIT] : hitLeaf;
-            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
+            if ((MODE == MODE_JOBS || (MODE == MODE_MIXED && !shadowLane)) && ranOff && hit) orig = COMPACT ? a.leafRef[hitLeaf & ~PT_LEAF_BIT] : hitLeaf;
+            store(hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
             active = false;
         }
         }   /* if (active) */

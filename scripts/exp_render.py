@@ -16,7 +16,8 @@ ap.add_argument("--inflight", type=int, default=3)
 ap.add_argument("--reseed", type=int, default=0)
 ap.add_argument("--blocks", type=int, default=0, help="0 = library default")
 ap.add_argument("--refill", type=int, default=0, help="0 = library default")
-ap.add_argument("--shadow-stream", type=int, default=1)
+ap.add_argument("--shadow-stream", type=int, default=2)
+ap.add_argument("--merge", type=int, default=1)
 args = ap.parse_args()
 if args.scene == "bunny":
     pos, aux, idx = pt.load_ply(os.path.join(ROOT, "tests", "golden", "models", "CBbunny.ply"))
@@ -37,6 +38,7 @@ ctx.set_constants(pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **c
 ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, args.inflight)
 ctx.set_option(core.OPT_RESEED, args.reseed)
 ctx.set_option(core.OPT_SHADOW_STREAM, args.shadow_stream)
+ctx.set_option(core.OPT_MERGE_PASSES, args.merge)
 if args.blocks:
     ctx.set_option(core.OPT_PERSIST_BLOCKS, args.blocks)
 if args.refill:
@@ -49,7 +51,7 @@ ctx.synchronize()
 dt = time.perf_counter() - t
 rc = ctx.render_sample(4 + args.frames, want_ray_counts=True)
 rays = int(rc[:2 * NR].sum())
-print(f"{args.scene} {W}x{H} slots {NR} traversal {args.traversal} in flight {args.inflight} blocks {args.blocks} refill {args.refill} reseed {args.reseed} shadow stream {args.shadow_stream}: {args.frames/dt:.2f} spp/s, {dt/args.frames*1e3:.2f} ms/frame, rays/sample {rays}, {rays*args.frames/dt/1e6:.0f} Mrays/s")
+print(f"{args.scene} {W}x{H} slots {NR} traversal {args.traversal} in flight {args.inflight} blocks {args.blocks} refill {args.refill} reseed {args.reseed} shadow stream {args.shadow_stream} merge {args.merge}: {args.frames/dt:.2f} spp/s, {dt/args.frames*1e3:.2f} ms/frame, rays/sample {rays}, {rays*args.frames/dt/1e6:.0f} Mrays/s")
 print("ray counts (closest, shadow) per depth:", rc[:2 * NR].reshape(-1, 2).tolist())
 acc = ctx.readback_accumulation()
 print("mean radiance", (acc[..., :3] / acc[..., 3:4]).mean(axis=(0, 1)))

@@ -307,6 +307,39 @@ def test_tonemap_and_frame_dump(gpu_ctx, oracle_lib, monkey, tmp_path):
     assert (tmp_path / "monkey.ppm").stat().st_size == len(f"P6\n{W} {H}\n255\n") + W * H * 3
 
 
+@pytest.mark.parametrize("trav", [core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED])
+@pytest.mark.parametrize("shadow_stream", [0, 1])
+def test_merged_passes_and_stream_options_change_nothing(gpu_ctx, oracle_lib, monkey, trav, shadow_stream):
+    """PT_OPT_MERGE_PASSES (the shadow rays of bounce d traced by the launch that traces the closest-hit rays of bounce
+    d + 1) and PT_OPT_SHADOW_STREAM: every buffer is what the separate passes leave - against the oracle in reference
+    order, against the separate passes byte for byte in the near-first order."""
+    W, H, NR, NF = 160, 88, 5, 5
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 3)
+    gpu_ctx.set_option(core.OPT_SHADOW_STREAM, shadow_stream)
+    try:
+        out = {}
+        for merge in (0, 1):
+            gpu_ctx.set_option(core.OPT_MERGE_PASSES, merge)
+            gpu_ctx.resize(W, H, NR)                       # fresh stacks and accumulation
+            gpu_ctx.set_constants(_consts(monkey, W, H, NR, 1, {}))
+            rc = gpu_ctx.render_samples(1, NF, want_ray_counts=True)
+            out[merge] = (gpu_ctx.readback_accumulation(), gpu_ctx.readback_current(), gpu_ctx.readback_raystack()[0], rc)
+        for k in range(3):
+            assert np.array_equal(np.asarray(out[0][k]).view(np.uint8), np.asarray(out[1][k]).view(np.uint8)), f"buffer {k} differs with merged passes"
+        assert np.array_equal(out[0][3], out[1][3])
+        if trav == core.TRAVERSAL_FLAT:
+            for frame in range(1, NF + 1):
+                oracle.render_frame(osc, fr, _consts(monkey, W, H, NR, frame, {}), mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+            _compare(gpu_ctx, fr, live_slots_only=True)
+    finally:
+        gpu_ctx.set_option(core.OPT_MERGE_PASSES, 0)
+        gpu_ctx.set_option(core.OPT_SHADOW_STREAM, 1)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
+
+
 @pytest.mark.parametrize("in_flight", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("reseed", [0, 1])
 def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_flight, reseed):
