@@ -286,13 +286,15 @@ enum {
                                     number of hardware queues; needs traversal 1 or 2 on 64 B or 48 B records, otherwise the
                                     passes stay apart.  Results do not depend on it */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
-                                    stack and pair of streams; results do not depend on it.  Three frames are six
-                                    streams, and HIP gives a process four hardware queues unless the environment
-                                    variable GPU_MAX_HW_QUEUES says otherwise when the runtime starts: with four, streams
-                                    share queues and wait on each other (about a tenth fewer frames per second at
-                                    1080p).  A host that renders with frames in flight should export
+                                    stack and stream; results do not depend on it.  With merged passes (the default
+                                    where PT_OPT_MERGE_PASSES applies) three frames are three streams and HIP's default
+                                    of four hardware queues per process is enough.  Where the passes stay apart
+                                    (traversal 3, treelet records) every frame in flight has a second stream; with four
+                                    queues, six streams share queues and wait on each other (about a fifth fewer frames
+                                    per second at 1080p).  A host that renders that way should export
                                     GPU_MAX_HW_QUEUES=8 (2 per frame in flight plus 2; never above 32) before its first
-                                    HIP call; the library cannot set it once the runtime is up */
+                                    HIP call - the library cannot set it once the runtime is up - or set
+                                    PT_OPT_SHADOW_STREAM = 0 */
 };
 PT_API int pt_set_option(PtContext* ctx, int option, int value);
 PT_API int pt_get_option(PtContext* ctx, int option, int* value);
