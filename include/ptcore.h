@@ -285,6 +285,17 @@ enum {
                                     half the launches, one stream per frame, and a frame rate that no longer hinges on the
                                     number of hardware queues; needs traversal 1 or 2 on 64 B or 48 B records, otherwise the
                                     passes stay apart.  Results do not depend on it */
+    PT_OPT_FRAME_TRAIN    = 14,  /* pt_render_sample[s]: 1 (default) = the frames of a call advance together, one bounce per step:
+                                    a step is one launch pass (the frame that enters), one traversal launch over the
+                                    closest-hit rays of every frame in flight and the shadow rays of the step before, one
+                                    resolve pass (the frame that leaves) and one shade pass, all on the context's stream;
+                                    numRays + 1 ray stacks are kept in a ring (48 B x W x H x slots each) and a call of N
+                                    frames takes N + numRays steps.  Serves traversals 1, 2 and 3 on 64 B records (1 and 2
+                                    on 48 B records); otherwise, and with 0, frames run one per pipe
+                                    (PT_OPT_FRAMES_IN_FLIGHT).  Every buffer comes out the same byte for byte */
+    PT_OPT_TRAIN_PARTS    = 15,  /* 1..4 (default 2): the frame train renders the image in this many bands of rows, each a train
+                                    of its own on its own stream (a pixel's path never leaves its band): while one band's
+                                    shade, launch and resolve passes run, another band's traversal launch has the GPU */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
                                     stack and stream; results do not depend on it.  With merged passes (the default
                                     where PT_OPT_MERGE_PASSES applies) three frames are three streams and HIP's default

@@ -41,6 +41,8 @@ OPT_SORT_RAYS = 9               # 0 = never, 1 = always, 2 = batches of 2^20 ray
 OPT_SORT_BITS = 10
 OPT_SHADOW_STREAM = 12
 OPT_MERGE_PASSES = 13
+OPT_TRAIN_PARTS = 15             # 1..4: bands of rows the frame train renders side by side
+OPT_FRAME_TRAIN = 14             # 1 (default): pt_render_samples steps its frames together, one traversal launch per step
 OPT_SECOND_WALK = 11            # certified walk's second pass: 0 = a ray per lane, 1 = a ray per wavefront (default)
 OPT_RECORD_LAYOUT = 8           # 0 = 64 B records, 1 = 48 B records, 2 = 128 B treelet records beside the 64 B ones
 LAYOUT_RECORDS64, LAYOUT_RECORDS48, LAYOUT_TREELETS = 0, 1, 2

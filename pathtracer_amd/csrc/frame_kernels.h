@@ -19,6 +19,8 @@
 
 #pragma clang fp contract(off)
 
+#define PT_MAX_TRAIN_DEPTH 64     /* deepest path (slots per pixel) the frame train keeps per-depth ray counts for */
+
 enum {
     CTR_NJOBS = 0,        /* entries of the current job list */
     CTR_FETCH_CLOSEST = 1,
@@ -32,6 +34,19 @@ enum {
    walk's fetch counter */
 __host__ __device__ constexpr uint32_t ctr_flag_base(uint32_t slots) { return CTR_SHADOW + 2u * slots; }
 __host__ __device__ constexpr uint32_t ctr_words(uint32_t slots) { return CTR_SHADOW + 4u * slots; }
+
+/* Counters of the frame train (several frames, each at its own depth, stepped together): the first three are the words the
+   shade pass already uses under the names above. */
+enum {
+    TC_NJOBS = 0,         /* entries of the step's job list: the survivors of the last step's shade pass + the new frame's pixels */
+    TC_FETCH = 1,
+    TC_OUT = 2,           /* entries the shade pass has appended to the next step's list */
+    TC_BASE = 3,          /* where the launch pass puts the new frame's jobs: behind the survivors */
+    TC_NSHADOW = 4,       /* two words: lengths of the two shadow queues (one is traced while the other is filled) */
+    TC_FLAG = 6,          /* certified walk: jobs listed for a second walk, that walk's fetch counter */
+    TC_LATE = 8,          /* jobs whose second walk runs beside the next step: count, fetch counter */
+    TC_WORDS = 16
+};
 
 struct FrameArgs {
     PtShaderConstants c;
@@ -57,6 +72,12 @@ struct FrameArgs {
     float4* accumulation;
     uint2* current;                  /* RGBA16F */
     unsigned long long* rayCounts;   /* [2*depth] closest rays, [2*depth+1] shadow rays */
+    /* frame train */
+    uint32_t slotBase;               /* launch: index of the frame's first slot in the ring of ray stacks (jobs carry ring-wide slot indices;
+                                        `stack` is the ring's base for the shade pass, the frame's own stack for launch and resolve) */
+    uint32_t row0, row1;             /* launch, resolve: the rows of the image this part of the train renders ([0, H) elsewhere) */
+    uint32_t injectNext;             /* step end: jobs the next step's launch pass will add */
+    uint32_t shadowQueue;            /* step end: the queue this step's traversal launch emptied */
 };
 
 __device__ __forceinline__ void mat_mul_vec(const float* m, const float v[4], float out[4])
@@ -65,15 +86,17 @@ __device__ __forceinline__ void mat_mul_vec(const float* m, const float v[4], fl
 }
 
 /* launch.comp:28-51 */
-__global__ __launch_bounds__(256) void k_launch(FrameArgs f)
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void k_launch_t(FrameArgs f)
 {
-    const uint32_t gx = blockIdx.x * 32 + (threadIdx.x & 31), gy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const uint32_t gx = blockIdx.x * 32 + (threadIdx.x & 31), gy = (TRAIN ? f.row0 : 0u) + blockIdx.y * 8 + (threadIdx.x >> 5);
     const uint32_t lx = gx + (uint32_t)f.c.viewportBase[0], ly = gy + (uint32_t)f.c.viewportBase[1];
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (!TRAIN && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
         f.ctr[CTR_NJOBS] = f.W * f.H;
         for (uint32_t k = 1; k < ctr_words(f.slots); k++) f.ctr[k] = 0;            /* the frame starts from clean counters */
     }
     if ((float)lx >= f.c.viewportSize[0] || (float)ly >= f.c.viewportSize[1]) return;
+    if (TRAIN && gy >= f.row1) return;
     uint32_t jitter = (uint32_t)f.blueNoise[(lx & 0xFF) + ((ly & 0xFF) << 8)] * 256u + (uint32_t)f.blueNoise[f.c.frameIndex & 0xFFFF];
     h16 wx, wy; WeylNth(jitter, wx, wy);
     float px = (((float)lx + (float)wx) / f.c.viewportSize[0]) * 2.0f - 1.0f;
@@ -98,21 +121,17 @@ __global__ __launch_bounds__(256) void k_launch(FrameArgs f)
     sp[0] = make_float4(d.x * inv, d.y * inv, d.z * inv, __uint_as_float(rs));
     sp[1] = make_float4(cam[0], cam[1], cam[2], __uint_as_float(0u));
     s->prob = 0;
-    f.jobs[jobIndex] = stackIndex;
+    /* (the step's counters were set when the last step ended; a part's jobs are its own rows') */
+    if (TRAIN) f.jobs[f.ctr[TC_BASE] + (jobIndex - f.row0 * (uint32_t)f.c.viewportSize[0])] = f.slotBase + stackIndex;
+    else f.jobs[jobIndex] = stackIndex;
 }
+#define k_launch k_launch_t<false>
 
-/* trace.comp:58-233 minus the two walks */
-#define PT_SHADE_BLOCK 256
-__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t depthIndex)
+/* trace.comp:58-233 minus the two walks: one job.  `depth` comes back for live jobs (hits always, misses where TRAIN asks). */
+template <bool TRAIN>
+__device__ __forceinline__ void shade_job(const FrameArgs& f, uint32_t j, uint32_t slot, bool live, bool& wantShadow, uint32_t& nextJob, PtShadowRay& sr,
+                                          uint32_t& depth)
 {
-    const uint32_t j = blockIdx.x * PT_SHADE_BLOCK + threadIdx.x;
-    const uint32_t njobs = f.ctr[CTR_NJOBS];
-    uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
-    const bool live = slot != PT_JOB_DEAD;
-    bool wantShadow = false;
-    uint32_t nextJob = PT_JOB_DEAD;
-    PtShadowRay sr;
-
     if (live) {
         PtRayStackSlot* s = f.stack + slot;
         const uint4* hp = (const uint4*)(f.hitRecs + j);
@@ -120,6 +139,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
         const int32_t i1 = (int32_t)h0.y, i2 = (int32_t)h0.z, i3 = (int32_t)h0.w;
         if (i1 < 0) {                                                          /* trace.comp:192-196; the job ends here */
             s->prob = 0;
+            if (TRAIN) depth = s->currentDepth;
             if (!f.fuseCompact) f.jobs[j] = PT_JOB_DEAD;
         } else {
             const float t = __uint_as_float(h0.x);
@@ -130,6 +150,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
             F3 rd = { s0.x, s0.y, s0.z }, ro = { s1.x, s1.y, s1.z };
             Rng rng; rng.rnd = __float_as_uint(s0.w);
             const uint32_t currentDepth = __float_as_uint(s1.w);
+            depth = currentDepth;
             F3 hitPos = { t * rd.x + ro.x, t * rd.y + ro.y, t * rd.z + ro.z };    /* trace.comp:198 */
 
             /* shadeHit, trace.comp:58-163 */
@@ -225,13 +246,19 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
         }
     }
 
-    /* Counts go to the device counters once per workgroup: one atomic per wavefront on the same word serialises in one
-     * L2 channel and was the larger part of this kernel's time.  Four wavefronts per workgroup is the measured optimum
-     * for the path tracer: with sixteen the atomics are fewer still, but a workgroup then needs sixteen free wave slots
-     * on one CU at once, which the persistent traversal kernels of the frames in flight rarely leave (201 against
-     * 220 spp/s at 1080p). */
-    __shared__ uint32_t shCount[3][PT_SHADE_BLOCK / 64];
-    __shared__ uint32_t shBase[2];
+}
+
+#define PT_SHADE_BLOCK 256
+/* What the shade pass hands on: the job's next entry (in place, the reference's way, trace.comp:222-226, or appended to the
+ * next, dense list) and its shadow ray.
+ * Counts go to the device counters once per workgroup: one atomic per wavefront on the same word serialises in one
+ * L2 channel and was the larger part of this kernel's time.  Four wavefronts per workgroup is the measured optimum
+ * for the path tracer: with sixteen the atomics are fewer still, but a workgroup then needs sixteen free wave slots
+ * on one CU at once, which the persistent traversal kernels of the frames in flight rarely leave (201 against
+ * 220 spp/s at 1080p).  Every thread of the workgroup calls this. */
+__device__ __forceinline__ void shade_emit(const FrameArgs& f, uint32_t j, bool live, bool wantShadow, uint32_t nextJob, const PtShadowRay& sr,
+                                           uint32_t (*shCount)[PT_SHADE_BLOCK / 64], uint32_t* shBase)
+{
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool cont = nextJob != PT_JOB_DEAD;
     const uint64_t cm = __ballot(cont), m = __ballot(wantShadow), lm = __ballot(live);
@@ -247,7 +274,6 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
     }
     __syncthreads();
 
-    /* the job's next entry: in place (the reference's way, trace.comp:222-226) or appended to the next, dense list */
     if (f.fuseCompact) {
         if (cont) f.jobsOut[shBase[0] + shCount[0][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0))] = nextJob;
     } else if (live && wantShadow) {
@@ -267,7 +293,73 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
         uint4* dst = (uint4*)(f.shadowRays + shBase[1] + shCount[1][wave] + rank);
         dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
     }
+}
+
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t depthIndex)
+{
+    __shared__ uint32_t shCount[3][PT_SHADE_BLOCK / 64];
+    __shared__ uint32_t shBase[2];
+    const uint32_t j = blockIdx.x * PT_SHADE_BLOCK + threadIdx.x;
+    const uint32_t njobs = f.ctr[CTR_NJOBS];
+    const uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
+    const bool live = slot != PT_JOB_DEAD;
+    bool wantShadow = false;
+    uint32_t nextJob = PT_JOB_DEAD, depth = 0;
+    PtShadowRay sr;
+    shade_job<false>(f, j, slot, live, wantShadow, nextJob, sr, depth);
+    shade_emit(f, j, live, wantShadow, nextJob, sr, shCount, shBase);
     (void)depthIndex;
+}
+
+/* The shade pass of the frame train: the step's job list holds jobs of several frames, each frame at its own depth, and its
+ * length is known on the device only, so a fixed number of workgroups walks the list in strides.  Ray counts are kept per
+ * depth (each job knows its own): per workgroup in LDS, one global atomic per depth and workgroup at the end. */
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_train(FrameArgs f)
+{
+    __shared__ uint32_t shCount[3][PT_SHADE_BLOCK / 64];
+    __shared__ uint32_t shBase[2];
+    __shared__ uint32_t shDepth[2][PT_MAX_TRAIN_DEPTH];
+    const int lane = threadIdx.x & 63;
+    for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) (&shDepth[0][0])[k] = 0;
+    __syncthreads();
+    const uint32_t njobs = f.ctr[TC_NJOBS];
+    const uint32_t stride = gridDim.x * PT_SHADE_BLOCK;
+    for (uint32_t base = blockIdx.x * PT_SHADE_BLOCK; base < njobs; base += stride) {     /* the same trips for every thread of a workgroup */
+        const uint32_t j = base + threadIdx.x;
+        const uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
+        const bool live = slot != PT_JOB_DEAD;
+        bool wantShadow = false;
+        uint32_t nextJob = PT_JOB_DEAD, depth = 0;
+        PtShadowRay sr;
+        shade_job<true>(f, j, slot, live, wantShadow, nextJob, sr, depth);
+        /* a wavefront's jobs are of one or two depths: one LDS atomic per depth present */
+        uint64_t todo = __ballot(live);
+        while (todo) {
+            const int first = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)depth, first);
+            const uint64_t same = __ballot(live && depth == d);
+            const uint64_t sh = __ballot(live && depth == d && wantShadow);
+            if (lane == first && d < PT_MAX_TRAIN_DEPTH) { atomicAdd(&shDepth[0][d], (uint32_t)__popcll(same)); if (sh) atomicAdd(&shDepth[1][d], (uint32_t)__popcll(sh)); }
+            todo &= ~same;
+        }
+        shade_emit(f, j, live, wantShadow, nextJob, sr, shCount, shBase);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) {
+        const uint32_t c = (&shDepth[0][0])[k];
+        if (c) atomicAdd(f.rayCounts + 2 * (k % PT_MAX_TRAIN_DEPTH) + k / PT_MAX_TRAIN_DEPTH, (unsigned long long)c);
+    }
+}
+
+/* Ends a step of the frame train; one thread.  The list the shade pass appended to becomes the next step's list, with room
+ * behind it for the frame that step's launch pass adds; the shadow queue this step's traversal launch emptied is free again. */
+__global__ void k_train_step_end(FrameArgs f)
+{
+    const uint32_t survivors = f.ctr[TC_OUT];
+    f.ctr[TC_BASE] = survivors;
+    f.ctr[TC_NJOBS] = survivors + f.injectNext;
+    f.ctr[TC_OUT] = 0; f.ctr[TC_FETCH] = 0;
+    f.ctr[TC_NSHADOW + f.shadowQueue] = 0;
 }
 
 /* Records the ray counts of one depth; one thread.  With the fused compaction it also hands the new list length
@@ -307,8 +399,8 @@ __global__ void k_compact_finish(FrameArgs f) { f.ctr[CTR_NJOBS] = f.ctr[CTR_COM
 /* composite.frag:30-55 */
 __global__ __launch_bounds__(256) void k_resolve(FrameArgs f)
 {
-    const uint32_t pix = blockIdx.x * 256 + threadIdx.x;
-    if (pix >= f.W * f.H) return;
+    const uint32_t pix = f.row0 * f.W + blockIdx.x * 256 + threadIdx.x;
+    if (pix >= f.row1 * f.W) return;
     const PtRayStackSlot* s = f.stack + (size_t)pix * f.c.numRays;
     float L[3] = { 0, 0, 0 };
     for (int depth = (int)f.c.numRays - 1; depth >= 0; depth--) {

@@ -120,6 +120,39 @@ struct FramePipe {
     int deferredShadow = -1;                              /* bounce whose shadow pass waits to run inside the next bounce's closest-hit launch */
 };
 
+/* The frame train: pt_render_samples steps all its frames in flight together, each one bounce further per step, on one
+ * stream.  A step is one launch pass (the frame that enters), ONE traversal launch over the closest-hit rays of every frame in
+ * flight and the shadow rays the last step's shade pass queued, one resolve pass (the frame that leaves) and ONE shade pass
+ * over all jobs.  Frame i enters at step i, is at depth d in step i + d and leaves in step i + numRays, so with numRays + 1
+ * frames in the ring a frame is finished every step, and the launches are as large as the chip likes them (ten million rays
+ * at 1080p x 8 bounces) instead of eight shrinking ones per frame that need several frames on several streams to fill the
+ * GPU.  Jobs carry ring-wide slot indices, so the traversal and shade kernels need not know which frame a job belongs to;
+ * the order in which a pixel's path is advanced is the same, so every buffer comes out byte for byte as frame-by-frame
+ * rendering leaves it. */
+enum { PT_MAX_TRAIN_PARTS = 4 };
+/* One part of the train: a band of rows of the image with its own job lists, hit records, shadow queues and counters, on
+ * its own stream.  A pixel's path and RNG chain never leave its part, so the parts are independent of each other; while
+ * one part's shade, launch and resolve passes run, or its traversal launch thins out towards its end, another part's
+ * traversal launch fills the GPU. */
+struct TrainPart {
+    uint32_t row0 = 0, row1 = 0;
+    uint64_t cap = 0;                 /* entries of each job list, of the hit records, of each shadow queue */
+    uint32_t* dJobs[2] = { nullptr, nullptr }; PtHitRec* dHitRecs = nullptr; PtShadowRay* dShadow[2] = { nullptr, nullptr };
+    uint32_t* dCtr = nullptr; uint32_t* dFlag = nullptr; uint32_t* dLate = nullptr;
+    hipStream_t stream = nullptr;     /* part 0: the context's stream */
+    hipEvent_t evDone = nullptr, evStagger = nullptr;
+};
+struct FrameTrain {
+    bool ready = false;
+    uint32_t F = 0;                   /* ray stacks in the ring */
+    int parts = 0;
+    PtRayStackSlot* dRing = nullptr;  /* F stacks of W x H x slots slots; every part works on its own rows of each */
+    unsigned long long* dRayCounts = nullptr;
+    TrainPart part[PT_MAX_TRAIN_PARTS];
+    uint32_t head = 0;                /* ring position of the most recent frame */
+    hipEvent_t evFork = nullptr;
+};
+
 struct PtContext {
     int device = 0;
     hipStream_t stream = nullptr;                         /* = pipe[0].stream: the stream the API's ordering promises refer to */
@@ -141,6 +174,8 @@ struct PtContext {
     /* per-resolution (bindings 5,6,9,10) */
     uint32_t W = 0, H = 0, slots = 0;
     FramePipe pipe[PT_MAX_PIPES];
+    FrameTrain train;
+    bool rngInTrain = false, lastInTrain = false;     /* the RNG states / the most recent frame live in the train's ring, at its head */
     int rngPipe = 0;            /* the pipe whose stack holds the RNG states the next launch continues from (launch.comp:49-50) */
     int lastPipe = 0;           /* the pipe of the most recent launch: what pt_readback_raystack returns */
     int resolvePipe = 0;        /* the pipe of the most recent resolve pass: accumulation adds stay in frame order */
@@ -153,7 +188,7 @@ struct PtContext {
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 1, optTrainParts = 2;
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
@@ -186,8 +221,36 @@ void free_pipe_buffers(FramePipe& p)
     p.ready = false; p.curJobs = 0;
     p.shadowBusy[0] = p.shadowBusy[1] = p.shade0Pending = p.donePending = false;
 }
+void free_train_buffers(FrameTrain& t)
+{
+    dfree(t.dRing); dfree(t.dRayCounts);
+    for (TrainPart& p : t.part) {
+        dfree(p.dJobs[0]); dfree(p.dJobs[1]); dfree(p.dHitRecs); dfree(p.dShadow[0]); dfree(p.dShadow[1]); dfree(p.dCtr); dfree(p.dFlag); dfree(p.dLate);
+        p.cap = 0;
+    }
+    t.ready = false; t.F = 0; t.parts = 0; t.head = 0;
+}
+void free_train(PtContext* c)        /* streams and events stay */
+{
+    free_train_buffers(c->train);
+    c->rngInTrain = c->lastInTrain = false;
+}
+void destroy_train(PtContext* c)
+{
+    free_train(c);
+    FrameTrain& t = c->train;
+    for (TrainPart& p : t.part) {
+        if (p.evDone) (void)hipEventDestroy(p.evDone);
+        if (p.evStagger) (void)hipEventDestroy(p.evStagger);
+        if (p.stream && p.stream != c->stream) (void)hipStreamDestroy(p.stream);
+        p = TrainPart();
+    }
+    if (t.evFork) (void)hipEventDestroy(t.evFork);
+    t = FrameTrain();
+}
 void free_frame(PtContext* c)
 {
+    free_train(c);
     for (FramePipe& p : c->pipe) free_pipe_buffers(p);
     dfree(c->dAccum); dfree(c->dCurrent);
     c->W = c->H = c->slots = 0;
@@ -220,6 +283,7 @@ int ensure_overflow(PtContext* ctx)
     uint64_t lanes = (uint64_t)grid_blocks(ctx) * PT_BLOCK;
     int areas = 2;
     for (int k = 1; k < PT_MAX_PIPES; k++) if (ctx->pipe[k].ready) areas = 2 * (k + 1);
+    if (areas < PT_MAX_TRAIN_PARTS) areas = PT_MAX_TRAIN_PARTS;      /* the frame train: one per part */
     if (need <= ctx->overflowEntries && lanes <= ctx->overflowLanes && areas <= ctx->overflowAreas && (ctx->dOverflow || need == 0)) return 0;
     for (FramePipe& p : ctx->pipe) { if (p.stream) (void)hipStreamSynchronize(p.stream); if (p.stream2) (void)hipStreamSynchronize(p.stream2); }
     dfree(ctx->dOverflow);
@@ -307,13 +371,13 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
 /* The closest-hit pass of one bounce and the shadow pass of the bounce before it as one launch (MODE_MIXED of k_trace_flat,
  * 64 B or 48 B records, traversals 1 and 2): both wait for the same shade pass and for nothing else, so one pool of rays keeps
  * more lanes busy than two launches side by side, and a frame needs one stream instead of two. */
-int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area)
+int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, bool train = false)
 {
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
     a.overflowEntries = ctx->overflowEntries;
     /* two passes' rays in one pool: one more workgroup per CU than a pass alone gets (measured: 3, 4, 5 -> 158, 160, 161 spp/s) */
-    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : 4)), block(PT_BLOCK);
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : (train ? 6 : 4))), block(PT_BLOCK);     /* the train's launches are batch-sized */
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
     const bool ordered = ctx->optTraversal != 1;
     if (ctx->compact) {
@@ -378,10 +442,12 @@ void fill_frame_args(PtContext* c, FramePipe& p, FrameArgs& f, uint32_t depth = 
     memset(&f, 0, sizeof(f));
     f.c = c->consts; f.W = c->W; f.H = c->H; f.slots = c->slots;
     f.zeroNextSlot = c->optStale ? 0u : 1u; f.reseed = c->optReseed ? 1u : 0u; f.seedFromJitter = c->accumEmpty ? 1u : 0u;
-    f.stack = p.dStack; f.rngStack = c->pipe[c->rngPipe].dStack;
+    f.stack = p.dStack;
+    f.rngStack = c->rngInTrain ? c->train.dRing + (size_t)c->train.head * c->W * c->H * c->slots : c->pipe[c->rngPipe].dStack;
     f.jobs = p.dJobs[p.curJobs]; f.jobsOut = p.dJobs[p.curJobs ^ 1]; f.ctr = p.dCtr; f.shadowCtr = p.dCtr + CTR_SHADOW + 2 * depth;
     f.hitRecs = p.dHitRecs; f.shadowRays = p.dShadow[0]; f.fuseCompact = 0; f.aux = c->dAux; f.lights = c->dLights; f.blueNoise = c->dBlueNoise;
     f.accumulation = c->dAccum; f.current = c->dCurrent; f.rayCounts = p.dRayCounts;
+    f.row0 = 0; f.row1 = c->H;
 }
 
 /* Streams, events and buffers of pipe k at the current resolution. */
@@ -441,6 +507,7 @@ int sync_all(PtContext* ctx)
         if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
         if (p.stream2) HIPCHK(hipStreamSynchronize(p.stream2));
     }
+    for (TrainPart& p : ctx->train.part) if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -488,7 +555,7 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
     (void)hipSetDevice(ctx->device);
     (void)sync_all(ctx);
     if (ctx->comm && g_nccl.CommDestroy) g_nccl.CommDestroy(ctx->comm);
-    free_scene(ctx); free_frame(ctx);
+    free_scene(ctx); free_frame(ctx); destroy_train(ctx);
     for (FramePipe& p : ctx->pipe) destroy_pipe(ctx, p);
     dfree(ctx->dFetch); dfree(ctx->dStats);
     dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); dfree(ctx->dSortBins);
@@ -526,6 +593,8 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_SORT_RAYS: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SORT_RAYS must be 0, 1 or 2"); ctx->optSortRays = value; return 0;
         case PT_OPT_SHADOW_STREAM: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SHADOW_STREAM must be 0, 1 or 2"); ctx->optShadowStream = value; return 0;
         case PT_OPT_MERGE_PASSES: ctx->optMergePasses = value != 0; return 0;
+        case PT_OPT_FRAME_TRAIN: ctx->optFrameTrain = value != 0; return 0;
+        case PT_OPT_TRAIN_PARTS: if (value < 1 || value > PT_MAX_TRAIN_PARTS) return ctx->fail(-1, "PT_OPT_TRAIN_PARTS must be 1..4"); ctx->optTrainParts = value; return 0;
         case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
@@ -545,6 +614,8 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_SECOND_WALK: *value = ctx->optSecondWalk; return 0;
         case PT_OPT_SHADOW_STREAM: *value = ctx->optShadowStream; return 0;
         case PT_OPT_MERGE_PASSES: *value = ctx->optMergePasses; return 0;
+        case PT_OPT_FRAME_TRAIN: *value = ctx->optFrameTrain; return 0;
+        case PT_OPT_TRAIN_PARTS: *value = ctx->optTrainParts; return 0;
         case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
         case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;
         case PT_OPT_RECORD_LAYOUT: *value = ctx->optRecordLayout; return 0;
@@ -720,13 +791,16 @@ static int launch_on(PtContext* ctx, FramePipe& p)
 {
     if (!ctx->dBlueNoise) return ctx->fail(-2, "pt_launch: scene was uploaded without a blue-noise table");
     FramePipe& src = ctx->pipe[ctx->rngPipe];
-    if (&src != &p && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(p.stream, src.evShade0, 0));
+    /* (states left by the frame train need no event: its work is on the context's stream, which every pipe's stream joins
+       before its first frame) */
+    if (!ctx->rngInTrain && &src != &p && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(p.stream, src.evShade0, 0));
     p.curJobs = 0; p.deferredShadow = -1;
     FrameArgs f; fill_frame_args(ctx, p, f);
     dim3 grid((ctx->W + 31) / 32, (ctx->H + 7) / 8), block(256);
     hipLaunchKernelGGL(k_launch, grid, block, 0, p.stream, f);
     HIPCHK(hipGetLastError());
     ctx->rngPipe = ctx->lastPipe = p.index;
+    ctx->rngInTrain = ctx->lastInTrain = false;
     return 0;
 }
 
@@ -891,6 +965,171 @@ static int frame_on(PtContext* ctx, FramePipe& p, uint32_t frame_index, int spec
     return resolve_on(ctx, p);
 }
 
+
+/* Buffers of the frame train for F stacks in the ring and `parts` bands of rows.  Returns 1 if the ring's slots do not fit a
+ * 32-bit index (the caller then renders frame by frame).  Rebuilding the ring keeps the stack at its head: the RNG states
+ * the next frame continues from and what pt_readback_raystack returns. */
+static int ensure_train(PtContext* ctx, uint32_t F, int parts)
+{
+    FrameTrain& t = ctx->train;
+    const size_t px = (size_t)ctx->W * ctx->H, stride = px * ctx->slots;
+    if ((uint64_t)F * stride >= 0xFFFFFFFFull) return 1;
+    if ((uint32_t)parts * 8u > ctx->H) parts = 1;
+    if (t.ready && t.F >= F && t.parts == parts) return 0;
+    if (!t.evFork) HIPCHK(hipEventCreateWithFlags(&t.evFork, hipEventDisableTiming));
+    for (int k = 0; k < parts; k++) {
+        TrainPart& p = t.part[k];
+        if (p.stream) continue;
+        if (k == 0) p.stream = ctx->stream;
+        else HIPCHK(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p.evStagger, hipEventDisableTiming));
+    }
+    for (TrainPart& p : t.part) if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (t.ready && F < t.F) F = t.F;                       /* a change of parts keeps the ring's size */
+    /* the head's stack survives in a buffer of its own while the ring is rebuilt */
+    PtRayStackSlot* keep = nullptr;
+    const bool carry = t.ready && (ctx->rngInTrain || ctx->lastInTrain);
+    if (carry) {
+        hipError_t e = hipMalloc((void**)&keep, stride * sizeof(PtRayStackSlot));
+        if (e != hipSuccess) return ctx->fail(-10, std::string("frame train: hipMalloc: ") + hipGetErrorString(e));
+        HIPCHK(hipMemcpy(keep, t.dRing + (size_t)t.head * stride, stride * sizeof(PtRayStackSlot), hipMemcpyDeviceToDevice));
+    }
+    free_train_buffers(t);
+    auto fail = [&](hipError_t e, const char* what) {
+        free_train_buffers(t); dfree(keep);
+        ctx->rngInTrain = ctx->lastInTrain = false;
+        return ctx->fail(-10, std::string(what) + ": " + hipGetErrorString(e));
+    };
+#define TRAIN_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) return fail(e_, "frame train: hipMalloc " #ptr); } while (0)
+    TRAIN_ALLOC(t.dRing, (size_t)F * stride * sizeof(PtRayStackSlot));
+    TRAIN_ALLOC(t.dRayCounts, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8);
+    for (int k = 0; k < parts; k++) {
+        TrainPart& p = t.part[k];
+        /* bands of whole 8-row blocks (the launch pass works in 32 x 8 tiles) */
+        const uint32_t blocks = (ctx->H + 7) / 8;
+        p.row0 = (uint32_t)((uint64_t)blocks * k / parts) * 8; p.row1 = (uint32_t)((uint64_t)blocks * (k + 1) / parts) * 8;
+        if (p.row1 > ctx->H) p.row1 = ctx->H;
+        p.cap = (uint64_t)(F < ctx->slots ? F : ctx->slots) * (p.row1 - p.row0) * ctx->W;
+        TRAIN_ALLOC(p.dJobs[0], p.cap * 4);
+        TRAIN_ALLOC(p.dJobs[1], p.cap * 4);
+        TRAIN_ALLOC(p.dHitRecs, p.cap * sizeof(PtHitRec));
+        TRAIN_ALLOC(p.dShadow[0], p.cap * sizeof(PtShadowRay));
+        TRAIN_ALLOC(p.dShadow[1], p.cap * sizeof(PtShadowRay));
+        TRAIN_ALLOC(p.dCtr, (size_t)TC_WORDS * 4);
+    }
+#undef TRAIN_ALLOC
+    t.F = F; t.parts = parts; t.head = 0;
+    /* queued on the context's stream, which every part's stream joins before its first step (see ensure_pipe) */
+    HIPCHK(hipMemsetAsync(t.dRing, 0, (size_t)F * stride * sizeof(PtRayStackSlot), ctx->stream));
+    HIPCHK(hipMemsetAsync(t.dRayCounts, 0, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8, ctx->stream));
+    if (carry) HIPCHK(hipMemcpyAsync(t.dRing, keep, stride * sizeof(PtRayStackSlot), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    dfree(keep);
+    t.ready = true;
+    return 0;
+}
+
+/* num_frames frames through the frame train. */
+static int train_render(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, uint64_t* ray_counts)
+{
+    FrameTrain& t = ctx->train;
+    const uint32_t nr = ctx->consts.numRays;
+    const size_t stride = (size_t)ctx->W * ctx->H * ctx->slots;
+    if (int rc = ensure_overflow(ctx)) return rc;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (ray_counts) HIPCHK(hipMemsetAsync(t.dRayCounts, 0, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8, ctx->stream));
+    /* where the most recent frame's RNG states are, if not in the ring already: the first launch pass reads them there */
+    const PtRayStackSlot* rngStack = ctx->rngInTrain ? t.dRing + (size_t)t.head * stride : ctx->pipe[ctx->rngPipe].dStack;
+    if (!ctx->rngInTrain) {
+        FramePipe& src = ctx->pipe[ctx->rngPipe];
+        if (src.stream && src.stream != ctx->stream && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(ctx->stream, src.evShade0, 0));
+    }
+    /* the other parts start after whatever is already queued on the context's stream */
+    HIPCHK(hipEventRecord(t.evFork, ctx->stream));
+    for (int k = 1; k < t.parts; k++) HIPCHK(hipStreamWaitEvent(t.part[k].stream, t.evFork, 0));
+    const uint32_t head0 = t.head;
+    auto pos_of = [&](uint32_t i) { return (head0 + 1u + i) % t.F; };
+    const bool seedFirst = ctx->accumEmpty;
+
+    FrameArgs f; fill_frame_args(ctx, ctx->pipe[0], f);
+    f.rayCounts = t.dRayCounts; f.fuseCompact = 1;
+    for (int k = 0; k < t.parts; k++) {
+        TrainPart& p = t.part[k];
+        HIPCHK(hipMemsetAsync(p.dCtr, 0, (size_t)TC_WORDS * 4, p.stream));
+        f.ctr = p.dCtr; f.injectNext = (p.row1 - p.row0) * ctx->W; f.shadowQueue = 0;
+        hipLaunchKernelGGL(k_train_step_end, dim3(1), dim3(1), 0, p.stream, f);          /* step 0 starts with the first frame's pixels */
+    }
+    int cur = 0, q = 0;
+    const uint32_t steps = num_frames + nr;
+    for (uint32_t s = 0; s < steps; s++) {
+        for (int k = 0; k < t.parts; k++) {
+            TrainPart& p = t.part[k];
+            const uint32_t ppx = (p.row1 - p.row0) * ctx->W;
+            f.ctr = p.dCtr; f.hitRecs = p.dHitRecs; f.row0 = p.row0; f.row1 = p.row1;
+            if (s < num_frames) {                                                             /* a frame enters */
+                const uint32_t pos = pos_of(s);
+                ctx->consts.frameIndex = (first_frame_index + s) & 0xFFFF;                      /* PathTracer.cpp:729 */
+                f.c = ctx->consts;
+                f.seedFromJitter = (s == 0 && seedFirst) ? 1u : 0u;                             /* launch.comp:49-50: its resolve pass follows within this call */
+                f.stack = t.dRing + (size_t)pos * stride; f.slotBase = (uint32_t)(pos * stride);
+                f.rngStack = s == 0 ? rngStack : t.dRing + (size_t)pos_of(s - 1) * stride;
+                f.jobs = p.dJobs[cur];
+                dim3 grid((ctx->W + 31) / 32, (p.row1 - p.row0 + 7) / 8), block(256);
+                hipLaunchKernelGGL(k_launch_t<true>, grid, block, 0, p.stream, f);
+            }
+            {   /* every frame in flight one bounce further, and the shadow rays of the bounce before */
+                TraceArgs a; fill_trace_args(ctx, a);
+                a.stack = t.dRing; a.hitRecs = p.dHitRecs;
+                a.jobs = p.dJobs[cur]; a.countPtr = p.dCtr + TC_NJOBS; a.fetchCounter = p.dCtr + TC_FETCH;
+                a.shadowRays = p.dShadow[q]; a.countPtr2 = p.dCtr + TC_NSHADOW + q;
+                if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
+            }
+            /* the parts start one after the other, so that their traversal launches do not all thin out at the same time */
+            if (s == 0 && k + 1 < t.parts) {
+                HIPCHK(hipEventRecord(p.evStagger, p.stream));
+                HIPCHK(hipStreamWaitEvent(t.part[k + 1].stream, p.evStagger, 0));
+            }
+            if (s >= nr) {                                                                    /* a frame leaves: its last shadow rays were in that launch */
+                f.stack = t.dRing + (size_t)pos_of(s - nr) * stride;
+                hipLaunchKernelGGL(k_resolve, dim3(((size_t)ppx + 255) / 256), dim3(256), 0, p.stream, f);
+            }
+            const uint32_t firstIn = s + 1 > nr ? s + 1 - nr : 0, lastIn = s < num_frames - 1 ? s : num_frames - 1;     /* frames with a job list entry this step */
+            if (firstIn <= lastIn) {
+                f.stack = t.dRing;
+                f.jobs = p.dJobs[cur]; f.jobsOut = p.dJobs[cur ^ 1];
+                f.shadowRays = p.dShadow[q ^ 1]; f.shadowCtr = p.dCtr + TC_NSHADOW + (q ^ 1);
+                const uint64_t most = (uint64_t)(lastIn - firstIn + 1) * ppx;
+                uint64_t blocks = (most + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
+                const uint64_t wide = (uint64_t)ctx->numCUs * 32;
+                if (blocks > wide) blocks = wide;
+                hipLaunchKernelGGL(k_shade_train, dim3((uint32_t)blocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f);
+            }
+            f.injectNext = s + 1 < num_frames ? ppx : 0u; f.shadowQueue = (uint32_t)q;
+            hipLaunchKernelGGL(k_train_step_end, dim3(1), dim3(1), 0, p.stream, f);
+            HIPCHK(hipGetLastError());
+        }
+        cur ^= 1; q ^= 1;
+    }
+    for (int k = 1; k < t.parts; k++) {      /* join: later calls on the context's stream see every part finished */
+        HIPCHK(hipEventRecord(t.part[k].evDone, t.part[k].stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, t.part[k].evDone, 0));
+    }
+    t.head = pos_of(num_frames - 1);
+    ctx->accumEmpty = false;
+    ctx->rngInTrain = ctx->lastInTrain = true;
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->evPending = true;
+    if (ray_counts) {
+        std::vector<unsigned long long> part((size_t)2 * PT_MAX_TRAIN_DEPTH);
+        HIPCHK(hipMemcpyAsync(part.data(), t.dRayCounts, part.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t j = 0; j < 2 * nr; j++) ray_counts[j] = part[j];
+    }
+    return 0;
+}
+
 PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, int speculative_depth0, uint64_t* ray_counts)
 try {
     if (!ctx) return -1;
@@ -899,6 +1138,15 @@ try {
     if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_render_sample: scene was uploaded without vertex attributes or lights");
     if (speculative_depth0 && (ctx->W % 8 || ctx->H % 8)) return ctx->fail(-1, "pt_render_sample: the speculative build needs W and H to be multiples of 8");
     if (num_frames == 0) return 0;
+    /* the frame train serves whatever its one traversal launch per step can: near-first and reference-order walks on 64 B
+       or 48 B records.  (The stale-slot behaviour needs every frame on the one ray stack; the voting build its own launches.) */
+    if (ctx->optFrameTrain && !ctx->optStale && !speculative_depth0 && (ctx->optTraversal == 1 || ctx->optTraversal == 2) && !ctx->dTreelets &&
+        ctx->consts.numRays <= PT_MAX_TRAIN_DEPTH) {
+        const uint32_t want = num_frames < ctx->consts.numRays + 1 ? num_frames : ctx->consts.numRays + 1;
+        const int rc = ensure_train(ctx, want, ctx->optTrainParts);
+        if (rc < 0) return rc;
+        if (rc == 0) return train_render(ctx, first_frame_index, num_frames, ray_counts);
+    }
     /* the reference's stale-slot behaviour needs every frame on the one ray stack */
     int K = ctx->optStale ? 1 : ctx->optFramesInFlight;
     if ((uint32_t)K > num_frames) K = (int)num_frames;
@@ -962,6 +1210,13 @@ PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob*
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
     FramePipe& p = ctx->pipe[ctx->lastPipe];           /* the stack and job list of the most recent frame */
+    if (ctx->lastInTrain) {
+        /* a frame the train rendered: its stack is the ring's head; its job list ended empty */
+        if (slots) HIPCHK(hipMemcpyAsync(slots, ctx->train.dRing + (size_t)ctx->train.head * px * ctx->slots, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyDeviceToHost, ctx->stream));
+        if (jobs) memset(jobs, 0xFF, px * 4);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return 0;
+    }
     if (slots) HIPCHK(hipMemcpyAsync(slots, p.dStack, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyDeviceToHost, ctx->stream));
     if (jobs) HIPCHK(hipMemcpyAsync(jobs, p.dJobs[p.curJobs], px * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -974,7 +1229,7 @@ PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
     FramePipe& p = ctx->pipe[0];                        /* the dispatch-site calls that follow work on pipe 0 */
-    if (slots) { HIPCHK(hipMemcpyAsync(p.dStack, slots, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyHostToDevice, ctx->stream)); ctx->rngPipe = 0; }
+    if (slots) { HIPCHK(hipMemcpyAsync(p.dStack, slots, px * ctx->slots * sizeof(PtRayStackSlot), hipMemcpyHostToDevice, ctx->stream)); ctx->rngPipe = 0; ctx->rngInTrain = false; }
     if (jobs) {
         /* a job is a slot index the kernels follow: one past the ray stack would be read and written on the device */
         const uint64_t limit = (uint64_t)px * ctx->slots;
@@ -984,7 +1239,7 @@ PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const
         HIPCHK(hipMemcpyAsync(p.dJobs[p.curJobs], jobs, px * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(hipMemcpyAsync(p.dCtr + CTR_NJOBS, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     }
-    ctx->lastPipe = 0;
+    ctx->lastPipe = 0; ctx->lastInTrain = false;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }

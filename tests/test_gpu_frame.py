@@ -23,7 +23,8 @@ def _setup(ctx, model, W, H, NR):
     lights, bn = pt.default_lights(), pt.load_blue_noise()
     helpers.upload(ctx, model, lights, bn)
     ctx.resize(W, H, NR)
-    for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0), (core.OPT_FRAMES_IN_FLIGHT, 2)):
+    for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0), (core.OPT_FRAMES_IN_FLIGHT, 2),
+                 (core.OPT_FRAME_TRAIN, 1), (core.OPT_TRAIN_PARTS, 2), (core.OPT_MERGE_PASSES, 1), (core.OPT_SHADOW_STREAM, 2)):
         ctx.set_option(o, v)
     return helpers.oracle_scene(model, lights, bn), oracle.Frame(W, H, NR)
 
@@ -318,6 +319,7 @@ def test_merged_passes_and_stream_options_change_nothing(gpu_ctx, oracle_lib, mo
     gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
     gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 3)
     gpu_ctx.set_option(core.OPT_SHADOW_STREAM, shadow_stream)
+    gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 0)            # these options are about frames that run one per pipe
     try:
         out = {}
         for merge in (0, 1):
@@ -334,8 +336,9 @@ def test_merged_passes_and_stream_options_change_nothing(gpu_ctx, oracle_lib, mo
                 oracle.render_frame(osc, fr, _consts(monkey, W, H, NR, frame, {}), mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
             _compare(gpu_ctx, fr, live_slots_only=True)
     finally:
-        gpu_ctx.set_option(core.OPT_MERGE_PASSES, 0)
-        gpu_ctx.set_option(core.OPT_SHADOW_STREAM, 1)
+        gpu_ctx.set_option(core.OPT_MERGE_PASSES, 1)
+        gpu_ctx.set_option(core.OPT_SHADOW_STREAM, 2)
+        gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
         gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
 
@@ -343,11 +346,12 @@ def test_merged_passes_and_stream_options_change_nothing(gpu_ctx, oracle_lib, mo
 @pytest.mark.parametrize("in_flight", [1, 2, 3, 4, 8])
 @pytest.mark.parametrize("reseed", [0, 1])
 def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_flight, reseed):
-    """pt_render_samples with several frames in flight leaves the ray stack, the current image and the accumulation of
-    the same frames rendered one after the other (the oracle does exactly that), and a pt_render_sample that follows
-    continues the RNG chain from the batch's last frame."""
+    """pt_render_samples with several frames in flight, one per pipe, leaves the ray stack, the current image and the
+    accumulation of the same frames rendered one after the other (the oracle does exactly that), and a pt_render_sample
+    that follows continues the RNG chain from the batch's last frame."""
     W, H, NR, NF = 160, 88, 4, 7
     osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 0)
     gpu_ctx.set_option(core.OPT_RESEED, reseed)
     gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, in_flight)
     mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS | (oracle.MODE_RESEED_EVERY_FRAME if reseed else 0)
@@ -365,6 +369,85 @@ def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_fligh
     oracle.render_frame(osc, fr, c, mode=mode)
     _compare(gpu_ctx, fr, live_slots_only=in_flight > 1)
     gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
+    gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
+
+
+@pytest.mark.parametrize("trav", [core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED, core.TRAVERSAL_CERTIFIED])
+@pytest.mark.parametrize("reseed,parts", [(0, 1), (0, 2), (1, 3), (0, 4)])
+def test_frame_train_equals_sequential(gpu_ctx, oracle_lib, monkey, trav, reseed, parts):
+    """The frame train (all frames of a call stepped together, one traversal launch and one shade pass per step): the
+    buffers are those of the same frames rendered one after the other, for calls shorter than, as long as and longer than the
+    ring (numRays + 1 stacks), with the ring growing between calls; per-depth ray counts equal the per-pipe pipeline's;
+    single frames, dispatch-site calls and the per-pipe pipeline continue the RNG chain from the train's last frame and
+    the train continues theirs."""
+    W, H, NR = 160, 88, 4
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
+    gpu_ctx.set_option(core.OPT_RESEED, reseed)
+    gpu_ctx.set_option(core.OPT_TRAIN_PARTS, parts)        # bands of rows, each a train of its own
+    mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS | (oracle.MODE_RESEED_EVERY_FRAME if reseed else 0)
+    near_first = trav == core.TRAVERSAL_FLAT_ORDERED
+    c = _consts(monkey, W, H, NR, 1, {})
+    gpu_ctx.set_constants(c)
+    frame = 1
+
+    def oracle_frames(n):
+        nonlocal frame
+        for _ in range(n):
+            c["frameIndex"] = frame
+            oracle.render_frame(osc, fr, c, mode=mode)
+            frame += 1
+
+    def check():
+        _compare(gpu_ctx, fr, strict=not near_first, live_slots_only=True)
+
+    counts = {}
+    for train in (1, 0):                                   # the same 11 frames by train and by pipes: equal ray counts per depth
+        gpu_ctx.set_option(core.OPT_FRAME_TRAIN, train)
+        gpu_ctx.resize(W, H, NR)
+        gpu_ctx.set_constants(c)
+        counts[train] = gpu_ctx.render_samples(1, 11, want_ray_counts=True)
+        if train:
+            first = (gpu_ctx.readback_accumulation(), gpu_ctx.readback_current())
+        else:
+            assert np.array_equal(first[0], gpu_ctx.readback_accumulation()) and np.array_equal(first[1], gpu_ctx.readback_current())
+    assert np.array_equal(counts[0], counts[1]) and int(counts[1][0]) == 11 * W * H
+    gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
+    gpu_ctx.resize(W, H, NR)
+    gpu_ctx.set_constants(c)
+    for n in (1, 2, 1, NR + 1, 3, 2 * NR + 3):                # the ring grows 1 -> 2 -> 5 stacks, then frames lap it
+        rc = gpu_ctx.render_samples(frame, n, want_ray_counts=True)
+        before = fr.ray_counts().copy()
+        oracle_frames(n)
+        check()
+        if not near_first:
+            after = fr.ray_counts()
+            assert int(rc[0::2][:NR].sum()) == int(after[0] - before[0]) and int(rc[1::2][:NR].sum()) == int(after[1] - before[1])
+    # dispatch sites one by one continue from the train's last frame ...
+    c["frameIndex"] = frame
+    gpu_ctx.set_constants(c)
+    gpu_ctx.launch()
+    for d in range(NR):
+        gpu_ctx.trace(d)
+    gpu_ctx.resolve_accumulate()
+    oracle_frames(1)
+    check()
+    # ... the train from theirs, the per-pipe pipeline from the train's, and the train from the pipes'
+    gpu_ctx.render_samples(frame, 3); oracle_frames(3); check()
+    gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 0)
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 3)
+    gpu_ctx.render_samples(frame, 4); oracle_frames(4); check()
+    gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
+    gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 1 if parts > 1 else 2)      # another number of bands: the ring is rebuilt, its head kept
+    gpu_ctx.render_samples(frame, 6); oracle_frames(6); check()
+    # a cleared accumulation reseeds exactly the first frame of the next call (launch.comp:49-50)
+    gpu_ctx.clear_accumulation(); fr.clear_accumulation()
+    gpu_ctx.render_samples(frame, 3); oracle_frames(3); check()
+    assert (gpu_ctx.readback_accumulation()[..., 3] == 3).all()
+    gpu_ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, 2)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+    gpu_ctx.set_option(core.OPT_RESEED, 0)
+    gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 2)
 
 
 def test_cornell_box_512_four_bounces(gpu_ctx, oracle_lib):
