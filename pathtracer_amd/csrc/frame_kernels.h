@@ -360,6 +360,7 @@ __global__ void k_train_step_end(FrameArgs f)
     f.ctr[TC_NJOBS] = survivors + f.injectNext;
     f.ctr[TC_OUT] = 0; f.ctr[TC_FETCH] = 0;
     f.ctr[TC_NSHADOW + f.shadowQueue] = 0;
+    f.ctr[TC_FLAG] = 0; f.ctr[TC_FLAG + 1] = 0;
 }
 
 /* Records the ray counts of one depth; one thread.  With the fused compaction it also hands the new list length

@@ -379,7 +379,7 @@ int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, boo
     /* two passes' rays in one pool: one more workgroup per CU than a pass alone gets (measured: 3, 4, 5 -> 158, 160, 161 spp/s) */
     dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : (train ? 6 : 4))), block(PT_BLOCK);     /* the train's launches are batch-sized */
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
-    const bool ordered = ctx->optTraversal != 1;
+    const bool ordered = ctx->optTraversal == 2;      /* 3 comes here where the certified walk is not to be had: reference order */
     if (ctx->compact) {
         if (ordered) hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, true, false, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, false, false, true>), grid, block, 0, stream, a);
@@ -424,6 +424,26 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
     dim3 grid2(ctx->numCUs * 2);
     if (count) hipLaunchKernelGGL((k_trace_ref_wave<MODE, true>), grid2, block, 0, stream, b);
     else hipLaunchKernelGGL((k_trace_ref_wave<MODE, false>), grid2, block, 0, stream, b);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* The frame train's launch under traversal 3: the certified walk over the step's jobs, with the shadow rays of the step before
+ * riding along, then the reference-order walk over the jobs it listed. */
+int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, uint32_t* flag, uint32_t* ctr)
+{
+    if (int rc = ensure_overflow(ctx)) return rc;
+    a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
+    a.overflowEntries = ctx->overflowEntries;
+    a.flagList = flag; a.flagCount = ctr;
+    a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : 6)), block(PT_BLOCK);
+    hipLaunchKernelGGL((k_trace_cert<MODE_MIXED, false>), grid, block, 0, stream, a);
+    HIPCHK(hipGetLastError());
+    TraceArgs b = a;
+    b.order = flag; b.countPtr = ctr; b.countPtr2 = nullptr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
+    if (ctx->optSecondWalk == 0) return launch_trace<MODE_JOBS, false>(ctx, b, false, stream, area);
+    hipLaunchKernelGGL((k_trace_ref_wave<MODE_JOBS, false>), dim3(ctx->numCUs * 2), block, 0, stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1084,7 +1104,10 @@ static int train_render(PtContext* ctx, uint32_t first_frame_index, uint32_t num
                 a.stack = t.dRing; a.hitRecs = p.dHitRecs;
                 a.jobs = p.dJobs[cur]; a.countPtr = p.dCtr + TC_NJOBS; a.fetchCounter = p.dCtr + TC_FETCH;
                 a.shadowRays = p.dShadow[q]; a.countPtr2 = p.dCtr + TC_NSHADOW + q;
-                if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
+                if (ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest) {
+                    if (!p.dFlag) HIPCHK(hipMalloc((void**)&p.dFlag, p.cap * 4));
+                    if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG)) return rc;
+                } else if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
             }
             /* the parts start one after the other, so that their traversal launches do not all thin out at the same time */
             if (s == 0 && k + 1 < t.parts) {
@@ -1140,7 +1163,7 @@ try {
     if (num_frames == 0) return 0;
     /* the frame train serves whatever its one traversal launch per step can: near-first and reference-order walks on 64 B
        or 48 B records.  (The stale-slot behaviour needs every frame on the one ray stack; the voting build its own launches.) */
-    if (ctx->optFrameTrain && !ctx->optStale && !speculative_depth0 && (ctx->optTraversal == 1 || ctx->optTraversal == 2) && !ctx->dTreelets &&
+    if (ctx->optFrameTrain && !ctx->optStale && !speculative_depth0 && ctx->optTraversal != 0 && !ctx->dTreelets &&
         ctx->consts.numRays <= PT_MAX_TRAIN_DEPTH) {
         const uint32_t want = num_frames < ctx->consts.numRays + 1 ? num_frames : ctx->consts.numRays + 1;
         const int rc = ensure_train(ctx, want, ctx->optTrainParts);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scan(uint32_t* binCount, 
     for (int k = 0; k < per; k++) { cursor[t * per + k] = run; run += c[k]; binCount[t * per + k] = 0; }
 }
 
-__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(uint64_t n, const uint16_t* keys, uint32_t* cursor, int nbins, uint32_t* order)
+__device__ __forceinline__ void bin_scatter_tile(uint64_t n, const uint16_t* keys, uint32_t* cursor, uint32_t* order)
 {
     /* The tile is first ordered inside LDS, then written out in that order: a tile's rays of one bin are one run in the
        output, so lanes next to each other write indices next to each other. */
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(uint64_t n, const
     for (int b = t; b < PT_SORT_BINS; b += PT_SORT_BLOCK) hist[b] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * PT_SORT_TILE;
+    if (base >= n) return;                                /* the same for the whole workgroup */
     const uint32_t count = (uint32_t)((n - base < PT_SORT_TILE) ? n - base : PT_SORT_TILE);
     for (uint32_t k = t; k < count; k += PT_SORT_BLOCK) atomicAdd(&hist[keys[base + k]], 1u);
     __syncthreads();
@@ -112,5 +113,9 @@ __global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(uint64_t n, const
         const uint32_t k = local[pos];
         order[gbase[keys[base + k]] + pos] = (uint32_t)(base + k);
     }
+}
+__global__ __launch_bounds__(PT_SORT_BLOCK) void k_bin_scatter(uint64_t n, const uint16_t* keys, uint32_t* cursor, int nbins, uint32_t* order)
+{
+    bin_scatter_tile(n, keys, cursor, order);
     (void)nbins;
 }

@@ -1014,7 +1014,10 @@ __device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float 
     boundL = __builtin_fmaf(-fabsf(eL), PT_CERT_SLACK, eL); boundR = __builtin_fmaf(-fabsf(eR), PT_CERT_SLACK, eR);
 }
 
-template <int MODE, bool COUNT>      /* MODE_RAYS or MODE_JOBS */
+/* MODE_RAYS, MODE_JOBS, or MODE_MIXED: a job list and, behind it, a shadow queue in one pool (see k_trace_flat).  A lane with
+ * a shadow ray walks near child first with the reference's own culling and stops at the first hit: nothing about an any-hit
+ * verdict depends on the order, so there is nothing to certify. */
+template <int MODE, bool COUNT>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
 {
     __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
@@ -1023,11 +1026,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
-    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
     bool active = false, pend = false;
+    bool shadowLane = false, freshShadow = false;      /* MODE_MIXED: what kind of ray the lane walks / has just loaded */
     uint32_t pendIdx = 0;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
@@ -1045,9 +1050,20 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
 
     auto flag_ray = [&]() { a.flagList[atomicAdd(a.flagCount, 1u)] = (uint32_t)id; };
+    auto issue = [&](uint64_t rid, RayWords& w) -> bool {
+        if (MODE != MODE_MIXED) return issue_ray<MODE>(a, rid, w);
+        freshShadow = rid >= numJobs;
+        return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
+    };
+    auto store = [&](bool h) {
+        if (MODE != MODE_MIXED) store_result<MODE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
+        else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, r.max_t, -1, -1, -1, 0, 0, 0, 0u);
+        else store_result<MODE_JOBS>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
+    };
 
     auto start_ray = [&](const RayWords& w) {
-        finish_ray<MODE>(w, r, exclude, tag);
+        if (MODE != MODE_MIXED) finish_ray<MODE>(w, r, exclude, tag);
+        else { shadowLane = freshShadow; if (shadowLane) finish_ray<MODE_SHADOW>(w, r, exclude, tag); else finish_ray<MODE_JOBS>(w, r, exclude, tag); }
         if (COUNT) { nRay++; nBox++; }
         hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
         limit0 = r.max_t; otherT = __builtin_huge_valf();
@@ -1056,9 +1072,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         /* finite and non-zero, all nine: x - x is 0 exactly then, NaN for an infinity or a NaN */
         const float probe = (invx - invx) + (invy - invy) + (invz - invz) + (r.o.x - r.o.x) + (r.o.y - r.o.y) + (r.o.z - r.o.z) +
                             (r.d.x - r.d.x) + (r.d.y - r.d.y) + (r.d.z - r.d.z);
-        const bool walkable = probe == 0.0f && invx != 0.0f && invy != 0.0f && invz != 0.0f;
+        const bool walkable = shadowLane || (probe == 0.0f && invx != 0.0f && invy != 0.0f && invz != 0.0f);
         float ftmin;
-        if (MODE == MODE_JOBS) {
+        nearLast = false;
+        if (MODE == MODE_JOBS || (MODE == MODE_MIXED && !shadowLane)) {
             /* what the shade pass is told besides the hit - whether the reference's walk went on into the last node of
                its array (intersections.glsl:109-113) - depends on that walk's max_t when it got there.  It cannot have
                gone in if the order-independent part of that node's box test fails, which is the case for all but a
@@ -1067,9 +1084,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
                                   hfrombits(a.lastH[3]), hfrombits(a.lastH[4]), hfrombits(a.lastH[5]), ftmin);
         }
         bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
-        if (!walkable) { flag_ray(); store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0); }
+        if (!walkable) { flag_ray(); store(false); }
         else if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }          /* the root's test is the reference's own: it comes first in every order */
-        else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
+        else store(false);
     };
 
     for (;;) {
@@ -1079,12 +1096,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         if (nIdle == 64 && pool.exhausted()) break;
         bool fresh = false;
         RayWords w;
-        if (pend) { id = pendIdx; pend = false; fresh = issue_ray<MODE>(a, id, w); }
+        if (pend) { id = pendIdx; pend = false; fresh = issue(id, w); }
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
             if (canTake && nid != ~0ull) {
                 if (a.order) { pendIdx = a.order[nid]; pend = true; }
-                else { id = nid; fresh = issue_ray<MODE>(a, id, w); }
+                else { id = nid; fresh = issue(id, w); }
             }
         }
 
@@ -1105,7 +1122,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
             F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
             F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
-            tri_test(r, p1, e1, e2, t, al, be, ga);
+            const bool accepted = tri_test(r, p1, e1, e2, t, al, be, ga);
+            if (MODE == MODE_MIXED && shadowLane) {
+                /* any hit ends the walk, except the triangle the ray starts on (intersections.glsl:81) */
+                if (accepted && (exclude == 0 || exclude != q3.x)) { hit = true; r.max_t = t; done = true; needPop = false; }
+            } else
             /* intersections.glsl:45 in its positive form, against the ray's own limit first */
             if (t >= r.min_t && t <= limit0 && al >= 0.0f && be >= 0.0f && ga >= 0.0f) {
                 if (t <= r.max_t) {                         /* the reference's acceptance: replaces the hit held */
@@ -1129,7 +1150,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             /* a subtree with a triangle too thin for its test to mean anything geometric is never skipped on distance */
             if (q3.w & 1u) boundL = NEG_INF;
             if (q3.w & 2u) boundR = NEG_INF;
-            const bool pL = sL && !(boundL > reach), pR = sR && !(boundR > reach);
+            bool pL = sL && !(boundL > reach), pR = sR && !(boundR > reach);
+            if (MODE == MODE_MIXED && shadowLane) {       /* the reference's own culling; the stack keeps tmin where the bound would be */
+                pL = sL && r.max_t > tminL; pR = sR && r.max_t > tminR;
+                boundL = tminL; boundR = tminR;
+            }
             const uint32_t refL = q3.x, refR = q3.y;
             const bool rightFirst = pL && pR && tminR < tminL;
             if (pL && pR) {
@@ -1156,12 +1181,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             uint32_t ref = sRef[wave][e][lane]; uint16_t bb = sBound[wave][e][lane], gb = sGate[wave][e][lane];
             asm volatile("" : "+v"(ref));
             if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; bb = (uint16_t)o.y; gb = (uint16_t)(o.y >> 16); }
-            if (!((float)hfrombits(bb) > fmaxf(r.max_t, hitGate))) { cur = ref; pathGate = (float)hfrombits(gb); needPop = false; }
+            const float waiting = (float)hfrombits(bb);
+            const bool enter = (MODE == MODE_MIXED && shadowLane) ? r.max_t > waiting : !(waiting > fmaxf(r.max_t, hitGate));
+            if (enter) { cur = ref; pathGate = (float)hfrombits(gb); needPop = false; }
         }
 
         if (done) {
-            if (hit && (tie || nearLast || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
-            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
+            if (!(MODE == MODE_MIXED && shadowLane) && hit && (tie || nearLast || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
+            store(hit);
             active = false;
         }
         }   /* if (active) */

@@ -1,50 +1,47 @@
-"""Experiment: frames per second of pt_render_samples over frames in flight, launch width and refill threshold (GPU box).
-One scene build, many option settings; the number of hardware queues is the process's (GPU_MAX_HW_QUEUES)."""
-import argparse, os, sys, time
+"""Experiment: frames per second of pt_render_samples over the options of the frame pipeline (GPU box).  One scene build,
+many option settings; the number of hardware queues is the process's (GPU_MAX_HW_QUEUES)."""
+import argparse, itertools, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pathtracer_amd as pt
 from pathtracer_amd import core
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="sanmiguel")
-ap.add_argument("--traversal", type=int, default=2)
-ap.add_argument("--frames", type=int, default=36)
-ap.add_argument("--inflight", default="1,2,3,4,6,8")
-ap.add_argument("--blocks", default="0")
-ap.add_argument("--refill", default="0")
-ap.add_argument("--merge", default="1")
+ap.add_argument("--traversal", default="2")
+ap.add_argument("--frames", type=int, default=120)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--layout", type=int, default=0)
-ap.add_argument("--train", default="1")
-ap.add_argument("--parts", default="2")
+ap.add_argument("--bits", type=int, default=4)
+lists = ("train", "parts", "merge", "blocks", "refill", "inflight")
+defaults = dict(train="1", parts="2", merge="1", blocks="0", refill="0", inflight="3")
+for name in lists:
+    ap.add_argument("--" + name, default=defaults[name])
 args = ap.parse_args()
 if args.scene == "sanmiguel":
     pos, aux, idx = pt.scenes.san_miguel_like(); cam = dict(pt.scenes.COURTYARD_CAMERA)
 else:
     pos, aux, idx = pt.scenes.sponza_like(); cam = dict(pt.scenes.SPONZA_CAMERA)
 nodes, ridx, _ = pt.build_bvh(pos, idx, 16)
-W, H, NR = 1920, 1080, 8
+W, H, NR = args.width, args.height, 8
 print("hardware queues:", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
-for parts in [int(v) for v in args.parts.split(",")]:
- for train in [int(v) for v in args.train.split(",")]:
-  for merge in [int(v) for v in args.merge.split(",")]:
-    for blocks in [int(v) for v in args.blocks.split(",")]:
-        for refill in [int(v) for v in args.refill.split(",")]:
-            for inflight in [int(v) for v in args.inflight.split(",")]:
-                ctx = pt.PathTracer(0)
-                ctx.set_option(core.OPT_RECORD_LAYOUT, args.layout)
-                ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
-                ctx.set_option(core.OPT_TRAVERSAL, args.traversal)
-                ctx.resize(W, H, NR)
-                ctx.set_constants(pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **cam))
-                ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, inflight)
-                ctx.set_option(core.OPT_MERGE_PASSES, merge)
-                ctx.set_option(core.OPT_FRAME_TRAIN, train)
-                ctx.set_option(core.OPT_TRAIN_PARTS, parts)
-                if blocks: ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
-                if refill: ctx.set_option(core.OPT_REFILL_MIN, refill)
-                ctx.render_samples(1, 2 * inflight); ctx.synchronize()
-                t = time.perf_counter()
-                ctx.render_samples(100, args.frames); ctx.synchronize()
-                dt = time.perf_counter() - t
-                print(f"parts {parts} train {train} layout {args.layout} {args.scene} traversal {args.traversal} merge {merge} blocks {blocks} refill {refill} in flight {inflight}: {args.frames / dt:.1f} spp/s", flush=True)
-                ctx.close()
+grid = [[int(v) for v in getattr(args, name).split(",")] for name in lists]
+for trav in [int(v) for v in args.traversal.split(",")]:
+    for train, parts, merge, blocks, refill, inflight in itertools.product(*grid):
+        ctx = pt.PathTracer(0)
+        ctx.set_option(core.OPT_RECORD_LAYOUT, args.layout)
+        ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
+        ctx.set_option(core.OPT_TRAVERSAL, trav)
+        ctx.resize(W, H, NR)
+        ctx.set_constants(pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **cam))
+        for o, v in ((core.OPT_FRAMES_IN_FLIGHT, inflight), (core.OPT_MERGE_PASSES, merge), (core.OPT_FRAME_TRAIN, train), (core.OPT_TRAIN_PARTS, parts)):
+            ctx.set_option(o, v)
+        if blocks: ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
+        if refill: ctx.set_option(core.OPT_REFILL_MIN, refill)
+        ctx.render_samples(1, 12); ctx.synchronize()
+        t = time.perf_counter()
+        ctx.render_samples(100, args.frames); ctx.synchronize()
+        dt = time.perf_counter() - t
+        print(f"{args.scene} {W}x{H} traversal {trav} train {train} parts {parts} merge {merge} blocks {blocks} refill {refill} in flight {inflight}: "
+              f"{args.frames / dt:.1f} spp/s ({args.frames} frames in {args.frames + NR if train else args.frames} steps)", flush=True)
+        ctx.close()
