@@ -255,7 +255,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extra:
         try:
             result["extra"] = {"certified_walk": certified, "san_miguel_stand_in": path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0])}
-            result["extra"]["san_miguel_stand_in_4k"] = path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 12)
+            result["extra"]["san_miguel_stand_in_4k"] = path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 48)
             result["extra"]["san_miguel_stand_in_certified_frames"] = certified_frames(ctx, ridx.shape[0], nodes.shape[0])
             spos, saux, sidx = pt.scenes.sponza_like()
             snodes, sridx, _ = pt.build_bvh(spos, sidx, threads)
@@ -265,7 +265,7 @@ def main():
             result["extra"] = {"error": str(e)}
     if world > 1 and not args.no_extra:
         extra = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend)
-        extra4k = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend, 3840, 2160, 8)
+        extra4k = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend, 3840, 2160, 32)
         if rank == 0:
             result["extra"] = {"san_miguel_stand_in_partitioned": extra, "san_miguel_stand_in_partitioned_4k": extra4k}
     ctx.close()
@@ -366,7 +366,7 @@ def certified_frames(ctx, num_triangles, num_nodes):
     six frames from a cleared buffer is, byte for byte, that of the reference-order walk (= 1) and of the default (= 2)."""
     import pathtracer_amd as pt
     from pathtracer_amd import core
-    W, H, NR, nf = 1920, 1080, 8, 12
+    W, H, NR, nf = 1920, 1080, 8, 120
     ctx.resize(W, H, NR)
     ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
     acc = {}
@@ -377,40 +377,42 @@ def certified_frames(ctx, num_triangles, num_nodes):
             ctx.render_samples(1, 6)
             acc[trav] = ctx.readback_accumulation()
         ctx.set_option(core.OPT_TRAVERSAL, 3)
+        ctx.render_samples(7, NR + 1)
         ctx.synchronize()
         t = time.perf_counter()
-        ctx.render_samples(7, nf)
+        ctx.render_samples(20, nf)
         ctx.synchronize()
         dt = time.perf_counter() - t
     finally:
         ctx.set_option(core.OPT_TRAVERSAL, 2)
     differ = lambda a, b: int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())
-    return {"spp_per_s_1080p": round(nf / dt, 2), "frames_in_flight": ctx.get_option(core.OPT_FRAMES_IN_FLIGHT),
+    return {"spp_per_s_1080p": round(nf / dt, 2), "frames_timed": nf,
             "pixels_differing_from_the_reference_order_walk_after_6_frames": differ(acc[3], acc[1]),
             "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
 
 
-def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=30, camera=None):
+def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=120, camera=None):
     """Context number: samples per pixel per second of the wavefront path tracer at 1080p (or the size given), 8 bounces
-    with next-event estimation, on the scene the context holds (BASELINE configs[2] shape); frames in flight at the
-    library default."""
+    with next-event estimation, on the scene the context holds (BASELINE configs[2] shape), library defaults: one
+    pt_render_samples call of nf frames through the frame train, which takes nf + 8 steps (the eight that fill and drain the
+    ring are inside the timed region)."""
     import pathtracer_amd as pt
     NR = 8
     ctx.resize(W, H, NR)
     ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **(camera or pt.scenes.COURTYARD_CAMERA)))
-    ctx.render_samples(1, 3)
+    ctx.render_samples(1, NR + 1)          # warm-up: brings the ring of ray stacks to its full size
     ctx.synchronize()
     t = time.perf_counter()
-    ctx.render_samples(4, nf)
+    ctx.render_samples(100, nf)
     ctx.synchronize()
     dt = time.perf_counter() - t
-    rc = ctx.render_sample(4 + nf, want_ray_counts=True)
+    rc = ctx.render_sample(100 + nf, want_ray_counts=True)
     rays = int(rc[:2 * NR].sum())
-    return {f"spp_per_s_{H}p": round(nf / dt, 2), "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
+    return {f"spp_per_s_{H}p": round(nf / dt, 2), "frames_timed": nf, "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
             "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1)}
 
 
-def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, backend, W=1920, H=1080, nf=24):
+def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, backend, W=1920, H=1080, nf=96):
     """Context number for N > 1: sample-partitioned rendering.  Every rank renders its own block of frame indices at
     1080p (or the size given; 3840 x 2160 is BASELINE configs[3]) x 8 bounces into its own accumulation buffer (per-frame reseed), then one all-reduce (RCCL) sums the RGBA32F
     buffers, .w = sample count included.  Every rank takes part in every collective whatever happens to it locally:
@@ -426,7 +428,7 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
         ctx.set_option(core.OPT_RESEED, 1)
         ctx.resize(W, H, NR)
         ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
-        ctx.render_samples(1 + rank * 3, 3)             # warm-up, also brings the extra frame pipes up
+        ctx.render_samples(1 + rank * 16, NR + 1)       # warm-up, also brings the ring of ray stacks to its full size
         ctx.clear_accumulation()
         ctx.synchronize()
     except Exception as e:
