@@ -296,16 +296,16 @@ enum {
     PT_OPT_TRAIN_PARTS    = 15,  /* 1..4 (default 2): the frame train renders the image in this many bands of rows, each a train
                                     of its own on its own stream (a pixel's path never leaves its band): while one band's
                                     shade, launch and resolve passes run, another band's traversal launch has the GPU */
-    PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames pt_render_samples keeps in flight, each on its own ray
-                                    stack and stream; results do not depend on it.  With merged passes (the default
-                                    where PT_OPT_MERGE_PASSES applies) three frames are three streams and HIP's default
-                                    of four hardware queues per process is enough.  Where the passes stay apart
-                                    (traversal 3, treelet records) every frame in flight has a second stream; with four
-                                    queues, six streams share queues and wait on each other (about a fifth fewer frames
-                                    per second at 1080p).  A host that renders that way should export
-                                    GPU_MAX_HW_QUEUES=8 (2 per frame in flight plus 2; never above 32) before its first
-                                    HIP call - the library cannot set it once the runtime is up - or set
-                                    PT_OPT_SHADOW_STREAM = 0 */
+    PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames the per-frame pipeline keeps in flight (PT_OPT_FRAME_TRAIN = 0, and what
+                                    the frame train does not serve), each on its own ray stack and stream; results do not
+                                    depend on it.  With merged passes three frames are three streams and HIP's default of
+                                    four hardware queues per process is enough.  Where the passes stay apart (traversal 3,
+                                    treelet records) every frame in flight has a second stream; with four queues, six
+                                    streams share queues and wait on each other (about a fifth fewer frames per second at
+                                    1080p).  A host that renders that way should export GPU_MAX_HW_QUEUES=8 (2 per frame in
+                                    flight plus 2; never above 32) before its first HIP call - the library cannot set it
+                                    once the runtime is up - or set PT_OPT_SHADOW_STREAM = 0.  The frame train uses two
+                                    streams whatever the options */
 };
 PT_API int pt_set_option(PtContext* ctx, int option, int value);
 PT_API int pt_get_option(PtContext* ctx, int option, int* value);
