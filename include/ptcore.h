@@ -396,9 +396,11 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
  * the call allocates and frees nothing: the ray-id counters, the ordering pass's bins, keys and order, the certified
  * walk's list and the spill area of the traversal stacks all live in one static device array of 52 MiB that every GPU
  * the library runs on holds from the first pt_ctx_create on it until the process ends.  Limits: at most 2^21
- * (2 097 152) rays per call (-1 beyond that), and a tree whose depth beyond the 12 stack entries kept in LDS fits the
- * array's 32 MiB spill area with at least one workgroup per CU (depth <= 76 on a 256-CU part; -1 otherwise; a deep
- * tree runs with fewer workgroups than pt_trace_rays would use).  All calls on one GPU share that GPU's array, from
+ * (2 097 152) rays per call (-1 beyond that), and a tree whose stack need beyond the 12 entries kept in LDS fits the
+ * array's 32 MiB spill area with at least one workgroup per CU (-1 otherwise; a deep tree runs with fewer workgroups
+ * than pt_trace_rays would use).  A walk over 64 B or 48 B records needs one stack entry per level of the tree, a walk
+ * over treelet records three per two levels: on a 256-CU part that is a depth of 76, or of 50 with
+ * PT_OPT_RECORD_LAYOUT = 2.  All calls on one GPU share that GPU's array, from
  * whatever context: calls that overlap in time on one GPU race; calls on one context are ordered on its stream. */
 PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits);
 /* Same with HOST pointers: copies in, traces, copies out. */

@@ -372,6 +372,32 @@ def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_fligh
     gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
 
 
+@pytest.mark.parametrize("shape", [(100, 50, 3, 3), (70, 44, 2, 4), (33, 9, 5, 5)])
+def test_frame_train_odd_shapes(gpu_ctx, monkey, shape):
+    """Widths that are no multiple of the launch pass's 32 x 8 tiles, heights that do not split into equal bands (or are too
+    small for the bands asked for), fewer bounces than slots: the train's accumulation, current image and per-depth ray
+    counts are those of the per-frame pipeline, byte for byte, for every number of bands."""
+    W, H, NR, slots = shape
+    helpers.upload(gpu_ctx, monkey, pt.default_lights(), pt.load_blue_noise())
+    out = {}
+    for train, parts in ((0, 1), (1, 1), (1, 2), (1, 3), (1, 4)):
+        gpu_ctx.resize(W, H, slots)
+        for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0), (core.OPT_FRAMES_IN_FLIGHT, 2),
+                     (core.OPT_FRAME_TRAIN, train), (core.OPT_TRAIN_PARTS, parts), (core.OPT_MERGE_PASSES, 1), (core.OPT_SHADOW_STREAM, 2)):
+            gpu_ctx.set_option(o, v)
+        gpu_ctx.set_constants(_consts(monkey, W, H, NR, 1, {}))
+        rc = gpu_ctx.render_samples(1, 9, want_ray_counts=True)
+        rc2 = gpu_ctx.render_samples(10, 2, want_ray_counts=True)
+        out[(train, parts)] = (gpu_ctx.readback_accumulation(), gpu_ctx.readback_current(), rc, rc2)
+    ref = out[(0, 1)]
+    assert int(ref[2][0]) == 9 * W * H and (ref[0][..., 3] == 11).all()
+    for key, got in out.items():
+        for k in range(4):
+            assert np.array_equal(np.asarray(ref[k]), np.asarray(got[k])), f"train, bands {key}: buffer {k} differs from the per-frame pipeline's"
+    gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 2)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+
+
 @pytest.mark.parametrize("trav", [core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED, core.TRAVERSAL_CERTIFIED])
 @pytest.mark.parametrize("reseed,parts", [(0, 1), (0, 2), (1, 3), (0, 4)])
 def test_frame_train_equals_sequential(gpu_ctx, oracle_lib, monkey, trav, reseed, parts):
