@@ -18,6 +18,8 @@ ap.add_argument("--blocks", type=int, default=0, help="0 = library default")
 ap.add_argument("--refill", type=int, default=0, help="0 = library default")
 ap.add_argument("--shadow-stream", type=int, default=2)
 ap.add_argument("--merge", type=int, default=1)
+ap.add_argument("--train", type=int, default=1)
+ap.add_argument("--parts", type=int, default=2)
 args = ap.parse_args()
 if args.scene == "bunny":
     pos, aux, idx = pt.load_ply(os.path.join(ROOT, "tests", "golden", "models", "CBbunny.ply"))
@@ -39,17 +41,19 @@ ctx.set_option(core.OPT_FRAMES_IN_FLIGHT, args.inflight)
 ctx.set_option(core.OPT_RESEED, args.reseed)
 ctx.set_option(core.OPT_SHADOW_STREAM, args.shadow_stream)
 ctx.set_option(core.OPT_MERGE_PASSES, args.merge)
+ctx.set_option(core.OPT_FRAME_TRAIN, args.train)
+ctx.set_option(core.OPT_TRAIN_PARTS, args.parts)
 if args.blocks:
     ctx.set_option(core.OPT_PERSIST_BLOCKS, args.blocks)
 if args.refill:
     ctx.set_option(core.OPT_REFILL_MIN, args.refill)
-ctx.render_samples(1, 3)
+ctx.render_samples(1, 9)
 ctx.synchronize()
 t = time.perf_counter()
-ctx.render_samples(4, args.frames)
+ctx.render_samples(20, args.frames)
 ctx.synchronize()
 dt = time.perf_counter() - t
-rc = ctx.render_sample(4 + args.frames, want_ray_counts=True)
+rc = ctx.render_sample(20 + args.frames, want_ray_counts=True)
 rays = int(rc[:2 * NR].sum())
 print(f"{args.scene} {W}x{H} slots {NR} traversal {args.traversal} in flight {args.inflight} blocks {args.blocks} refill {args.refill} reseed {args.reseed} shadow stream {args.shadow_stream} merge {args.merge}: {args.frames/dt:.2f} spp/s, {dt/args.frames*1e3:.2f} ms/frame, rays/sample {rays}, {rays*args.frames/dt/1e6:.0f} Mrays/s")
 print("ray counts (closest, shadow) per depth:", rc[:2 * NR].reshape(-1, 2).tolist())
