@@ -268,6 +268,56 @@ def test_ray_ordering_changes_nothing(gpu_ctx, bunny, traversal):
         ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
 
 
+@pytest.mark.parametrize("traversal", [core.TRAVERSAL_FLAT_ORDERED, core.TRAVERSAL_CERTIFIED])
+def test_back_to_back_batches_equal_one_at_a_time(gpu_ctx, courtyard_small, traversal):
+    """pt_trace_rays calls queued one behind the other without a wait in between (ordering scratch, counters and the
+    certified walk's list are reused from call to call) return the hits of the same batches traced one at a time with a wait
+    after each, byte for byte: different ray buffers of different sizes in turn, the same buffer twice, a batch too
+    small to fill an ordering tile in between, and a buffer rewritten by pt_generate_rays between two calls."""
+    ctx = gpu_ctx
+    helpers.upload(ctx, courtyard_small)
+    ctx.set_option(core.OPT_TRAVERSAL, traversal)
+    ctx.set_option(core.OPT_SORT_RAYS, 1)
+    sizes = [(1 << 20) + 333, 700_001, 1 << 20, 5000]
+    bufs = [(ctx.alloc(n * 32), ctx.alloc(n * 16), n) for n in sizes]
+    try:
+        for k, (r, _, n) in enumerate(bufs):
+            ctx.generate_rays(r, n, seed=100 + k)
+        order = [0, 1, 2, 3, 0, 0, 2, 1, 3, 1]
+        want = {}
+        for k in set(order):                                 # one at a time
+            r, h, n = bufs[k]
+            ctx.trace_rays_device(r, n, h)
+            ctx.synchronize()
+            want[k] = h.to_host(pt.HIT_DT, n).copy()
+            assert 0.05 < (want[k]["i1"] >= 0).mean() < 0.999
+        spare = [ctx.alloc(n * 16) for _, _, n in bufs]
+        got = []
+        for k in order:                                      # back to back, each into a buffer of its own turn
+            r, _, n = bufs[k]
+            h = ctx.alloc(n * 16)
+            ctx.trace_rays_device(r, n, h)
+            got.append((k, h, n))
+        for k, h, n in got:
+            assert np.array_equal(h.to_host(pt.HIT_DT, n).view(np.uint8), want[k].view(np.uint8)), f"batch {k} differs when traced back to back"
+            h.free()
+        # a buffer rewritten between two calls: the second call's order must be built from the new rays
+        r, h, n = bufs[0]
+        ctx.trace_rays_device(r, n, h)
+        ctx.generate_rays(r, n, seed=999)
+        ctx.trace_rays_device(r, n, spare[0])
+        ctx.trace_rays_device(r, n, h)
+        a, b = spare[0].to_host(pt.HIT_DT, n), h.to_host(pt.HIT_DT, n)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)) and not np.array_equal(a.view(np.uint8), want[0].view(np.uint8))
+        for x in spare:
+            x.free()
+    finally:
+        for r, h, _ in bufs:
+            r.free(); h.free()
+        ctx.set_option(core.OPT_SORT_RAYS, 2)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+
+
 @pytest.mark.parametrize("kind", ["unit", "flat", "sliver", "offset", "huge"])
 def test_random_triangle_soups_exact(gpu_ctx, oracle_lib, kind):
     """Bit-exact parity on many small random scenes of awkward shapes, all three traversal modes' bars."""
