@@ -26,6 +26,25 @@ def render_partitioned(render_frame, first_frame, num_frames, rank, world):
     return len(frames)
 
 
+def partition_block(first_frame, num_frames, rank, world):
+    """(first index, count) of the contiguous block of frame indices rank `rank` renders when the frames are dealt in blocks:
+    the first num_frames % world ranks get one frame more.  With the per-frame reseed the image of a set of frames does not
+    depend on who renders which, and one pt_render_samples call per rank lets the frame train run at its steady rate
+    (a call of n frames takes n + numRays steps)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    per, extra = divmod(num_frames, world)
+    return first_frame + rank * per + min(rank, extra), per + (1 if rank < extra else 0)
+
+
+def render_block(ctx, first_frame, num_frames, rank, world):
+    """Renders this rank's block with one pt_render_samples call; returns the number of frames rendered."""
+    first, count = partition_block(first_frame, num_frames, rank, world)
+    if count:
+        ctx.render_samples(first, count)
+    return count
+
+
 def allreduce_accumulation_torch(ctx, group=None):
     """Sums the accumulation buffers of all ranks in place with torch.distributed (RCCL on GPUs).
     The context's buffer is aliased as a torch tensor, no copy."""

@@ -44,8 +44,13 @@ def test_partition_is_a_partition():
         for nf in (0, 1, 7, 16):
             got = sorted(sum((ptd.partition_samples(5, nf, r, world) for r in range(world)), []))
             assert got == list(range(5, 5 + nf))
+            blocks = [ptd.partition_block(5, nf, r, world) for r in range(world)]
+            assert sorted(sum((list(range(f, f + c)) for f, c in blocks), [])) == list(range(5, 5 + nf))
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
     with pytest.raises(ValueError):
         ptd.partition_samples(0, 4, 2, 2)
+    with pytest.raises(ValueError):
+        ptd.partition_block(0, 4, 2, 2)
 
 
 def test_two_ranks_reproduce_single_process(tmp_path, oracle_lib):

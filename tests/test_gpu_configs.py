@@ -156,6 +156,13 @@ def test_sample_partition_sums_to_the_single_context_image(san_miguel, size):
             assert n == NF // world
         for c in ranks:
             parts.append(c.readback_accumulation())
+        # the same frames dealt in blocks, one pt_render_samples call per rank (what the frame train likes): the same sum
+        blocks = []
+        for rank, c in enumerate(ranks):
+            c.clear_accumulation()
+            assert ptd.render_block(c, 1, NF, rank, world) == NF // world
+        for c in ranks:
+            blocks.append(c.readback_accumulation())
             c.close()
         _prepare(single, san_miguel, W, H, NR, core.TRAVERSAL_FLAT_ORDERED, reseed=1, in_flight=2)
         single.render_samples(1, NF)
@@ -164,6 +171,7 @@ def test_sample_partition_sums_to_the_single_context_image(san_miguel, size):
         assert (parts[0][..., 3] == NF // world).all() and (parts[1][..., 3] == NF // world).all()
         assert np.array_equal(total[..., 3], whole[..., 3]) and (whole[..., 3] == NF).all()
         assert np.allclose(total, whole, rtol=1e-5, atol=1e-6)
+        assert np.array_equal((blocks[0] + blocks[1])[..., 3], whole[..., 3]) and np.allclose(blocks[0] + blocks[1], whole, rtol=1e-5, atol=1e-6)
     finally:
         for c in ranks:
             c.close()
