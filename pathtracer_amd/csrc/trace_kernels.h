@@ -1146,7 +1146,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             box_pair(r, rx, ry, rz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR);
             const f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
             float boundL, boundR;
-            /* (skipping the bounds in wavefronts that hold shadow rays only, by a vote, was measured: 133 against 157 spp/s) */
+            /* (skipping the bounds in wavefronts that hold shadow rays only, by a vote, was measured: 133 against 157 spp/s,
+               because the kernel then takes 90 registers instead of 83: five of its wavefronts per SIMD then leave 32
+               registers free instead of 72, and the second walk's wavefronts, which need 64, no longer fit beside them) */
             entry_bound(dx, dy, dz, invx, invy, invz, ax, ay, az, bx, by, bz, boundL, boundR);
             /* enter unless the order-independent part of the reference's verdict fails or the box certainly begins beyond
                everything that still matters */
