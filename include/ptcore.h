@@ -296,6 +296,10 @@ enum {
     PT_OPT_TRAIN_PARTS    = 15,  /* 1..4 (default 2): the frame train renders the image in this many bands of rows, each a train
                                     of its own on its own stream (a pixel's path never leaves its band): while one band's
                                     shade, launch and resolve passes run, another band's traversal launch has the GPU */
+    PT_OPT_TRAIN_MAX_MB   = 16,  /* 0 (default) = no limit; else the most device memory, in MiB, the frame train may take for its
+                                    ring of ray stacks and its lists (numRays + 1 stacks: 10 GiB at 1080p x 8 slots, 38 GiB
+                                    at 4K).  A call whose train would need more - or more than the device has free - renders
+                                    frame by frame instead, with the same results */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames the per-frame pipeline keeps in flight (PT_OPT_FRAME_TRAIN = 0, and what
                                     the frame train does not serve), each on its own ray stack and stream; results do not
                                     depend on it.  With merged passes three frames are three streams and HIP's default of

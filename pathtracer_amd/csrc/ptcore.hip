@@ -188,7 +188,7 @@ struct PtContext {
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 1, optTrainParts = 2;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 1, optTrainParts = 2, optTrainMaxMB = 0;
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
@@ -614,6 +614,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_SHADOW_STREAM: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SHADOW_STREAM must be 0, 1 or 2"); ctx->optShadowStream = value; return 0;
         case PT_OPT_MERGE_PASSES: ctx->optMergePasses = value != 0; return 0;
         case PT_OPT_FRAME_TRAIN: ctx->optFrameTrain = value != 0; return 0;
+        case PT_OPT_TRAIN_MAX_MB: if (value < 0) return ctx->fail(-1, "PT_OPT_TRAIN_MAX_MB must not be negative"); ctx->optTrainMaxMB = value; return 0;
         case PT_OPT_TRAIN_PARTS: if (value < 1 || value > PT_MAX_TRAIN_PARTS) return ctx->fail(-1, "PT_OPT_TRAIN_PARTS must be 1..4"); ctx->optTrainParts = value; return 0;
         case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
@@ -635,6 +636,7 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_SHADOW_STREAM: *value = ctx->optShadowStream; return 0;
         case PT_OPT_MERGE_PASSES: *value = ctx->optMergePasses; return 0;
         case PT_OPT_FRAME_TRAIN: *value = ctx->optFrameTrain; return 0;
+        case PT_OPT_TRAIN_MAX_MB: *value = ctx->optTrainMaxMB; return 0;
         case PT_OPT_TRAIN_PARTS: *value = ctx->optTrainParts; return 0;
         case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
         case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;
@@ -986,16 +988,41 @@ static int frame_on(PtContext* ctx, FramePipe& p, uint32_t frame_index, int spec
 }
 
 
-/* Buffers of the frame train for F stacks in the ring and `parts` bands of rows.  Returns 1 if the ring's slots do not fit a
- * 32-bit index (the caller then renders frame by frame).  Rebuilding the ring keeps the stack at its head: the RNG states
- * the next frame continues from and what pt_readback_raystack returns. */
+/* Device memory the frame train needs for F stacks and `parts` bands. */
+static uint64_t train_bytes(const PtContext* ctx, uint32_t F, int parts)
+{
+    const uint64_t px = (uint64_t)ctx->W * ctx->H;
+    const uint64_t cap = (uint64_t)(F < ctx->slots ? F : ctx->slots) * (px + (uint64_t)parts * 8 * ctx->W);     /* bands round up to 8 rows */
+    return (uint64_t)F * px * ctx->slots * sizeof(PtRayStackSlot) + cap * (2 * 4 + sizeof(PtHitRec) + 2 * sizeof(PtShadowRay));
+}
+
+/* Buffers of the frame train for F stacks in the ring and `parts` bands of rows.  Returns 1 if the train is not to be had -
+ * the ring's slots do not fit a 32-bit index, the memory it needs exceeds PT_OPT_TRAIN_MAX_MB or the device's free memory -
+ * and the caller renders frame by frame; the stack at the ring's head (the RNG states the next frame continues from, what
+ * pt_readback_raystack returns) then moves to pipe 0, and a ring that is rebuilt keeps it. */
 static int ensure_train(PtContext* ctx, uint32_t F, int parts)
 {
     FrameTrain& t = ctx->train;
     const size_t px = (size_t)ctx->W * ctx->H, stride = px * ctx->slots;
-    if ((uint64_t)F * stride >= 0xFFFFFFFFull) return 1;
     if ((uint32_t)parts * 8u > ctx->H) parts = 1;
     if (t.ready && t.F >= F && t.parts == parts) return 0;
+    if (t.ready && F < t.F) F = t.F;                       /* a change of parts keeps the ring's size */
+    for (TrainPart& p : t.part) if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const bool carry = t.ready && (ctx->rngInTrain || ctx->lastInTrain);
+    /* no train: what it holds that later frames need goes to pipe 0 (allocated since pt_resize), its buffers are freed */
+    auto give_up = [&](PtRayStackSlot* head) -> int {
+        FramePipe& p0 = ctx->pipe[0];
+        if (head && p0.dStack) {
+            HIPCHK(hipMemcpy(p0.dStack, head, stride * sizeof(PtRayStackSlot), hipMemcpyDeviceToDevice));
+            ctx->rngPipe = ctx->lastPipe = 0; p0.shade0Pending = false;
+        }
+        free_train_buffers(t);
+        ctx->rngInTrain = ctx->lastInTrain = false;
+        return 1;
+    };
+    if ((uint64_t)F * stride >= 0xFFFFFFFFull || (ctx->optTrainMaxMB > 0 && train_bytes(ctx, F, parts) > (uint64_t)ctx->optTrainMaxMB << 20))
+        return give_up(carry ? t.dRing + (size_t)t.head * stride : nullptr);
     if (!t.evFork) HIPCHK(hipEventCreateWithFlags(&t.evFork, hipEventDisableTiming));
     for (int k = 0; k < parts; k++) {
         TrainPart& p = t.part[k];
@@ -1005,26 +1032,17 @@ static int ensure_train(PtContext* ctx, uint32_t F, int parts)
         HIPCHK(hipEventCreateWithFlags(&p.evDone, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&p.evStagger, hipEventDisableTiming));
     }
-    for (TrainPart& p : t.part) if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (t.ready && F < t.F) F = t.F;                       /* a change of parts keeps the ring's size */
     /* the head's stack survives in a buffer of its own while the ring is rebuilt */
     PtRayStackSlot* keep = nullptr;
-    const bool carry = t.ready && (ctx->rngInTrain || ctx->lastInTrain);
     if (carry) {
-        hipError_t e = hipMalloc((void**)&keep, stride * sizeof(PtRayStackSlot));
-        if (e != hipSuccess) return ctx->fail(-10, std::string("frame train: hipMalloc: ") + hipGetErrorString(e));
+        if (hipMalloc((void**)&keep, stride * sizeof(PtRayStackSlot)) != hipSuccess) { (void)hipGetLastError(); return give_up(t.dRing + (size_t)t.head * stride); }
         HIPCHK(hipMemcpy(keep, t.dRing + (size_t)t.head * stride, stride * sizeof(PtRayStackSlot), hipMemcpyDeviceToDevice));
     }
     free_train_buffers(t);
-    auto fail = [&](hipError_t e, const char* what) {
-        free_train_buffers(t); dfree(keep);
-        ctx->rngInTrain = ctx->lastInTrain = false;
-        return ctx->fail(-10, std::string(what) + ": " + hipGetErrorString(e));
-    };
-#define TRAIN_ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) return fail(e_, "frame train: hipMalloc " #ptr); } while (0)
-    TRAIN_ALLOC(t.dRing, (size_t)F * stride * sizeof(PtRayStackSlot));
-    TRAIN_ALLOC(t.dRayCounts, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8);
+    bool short_of_memory = false;
+    auto alloc = [&](void** ptr, size_t bytes) { if (!short_of_memory && hipMalloc(ptr, bytes) != hipSuccess) { (void)hipGetLastError(); *ptr = nullptr; short_of_memory = true; } };
+    alloc((void**)&t.dRing, (size_t)F * stride * sizeof(PtRayStackSlot));
+    alloc((void**)&t.dRayCounts, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8);
     for (int k = 0; k < parts; k++) {
         TrainPart& p = t.part[k];
         /* bands of whole 8-row blocks (the launch pass works in 32 x 8 tiles) */
@@ -1032,14 +1050,18 @@ static int ensure_train(PtContext* ctx, uint32_t F, int parts)
         p.row0 = (uint32_t)((uint64_t)blocks * k / parts) * 8; p.row1 = (uint32_t)((uint64_t)blocks * (k + 1) / parts) * 8;
         if (p.row1 > ctx->H) p.row1 = ctx->H;
         p.cap = (uint64_t)(F < ctx->slots ? F : ctx->slots) * (p.row1 - p.row0) * ctx->W;
-        TRAIN_ALLOC(p.dJobs[0], p.cap * 4);
-        TRAIN_ALLOC(p.dJobs[1], p.cap * 4);
-        TRAIN_ALLOC(p.dHitRecs, p.cap * sizeof(PtHitRec));
-        TRAIN_ALLOC(p.dShadow[0], p.cap * sizeof(PtShadowRay));
-        TRAIN_ALLOC(p.dShadow[1], p.cap * sizeof(PtShadowRay));
-        TRAIN_ALLOC(p.dCtr, (size_t)TC_WORDS * 4);
+        alloc((void**)&p.dJobs[0], p.cap * 4);
+        alloc((void**)&p.dJobs[1], p.cap * 4);
+        alloc((void**)&p.dHitRecs, p.cap * sizeof(PtHitRec));
+        alloc((void**)&p.dShadow[0], p.cap * sizeof(PtShadowRay));
+        alloc((void**)&p.dShadow[1], p.cap * sizeof(PtShadowRay));
+        alloc((void**)&p.dCtr, (size_t)TC_WORDS * 4);
     }
-#undef TRAIN_ALLOC
+    if (short_of_memory) {                                  /* the device cannot hold the train: frame by frame, then */
+        const int rc = give_up(keep);
+        dfree(keep);
+        return rc;
+    }
     t.F = F; t.parts = parts; t.head = 0;
     /* queued on the context's stream, which every part's stream joins before its first step (see ensure_pipe) */
     HIPCHK(hipMemsetAsync(t.dRing, 0, (size_t)F * stride * sizeof(PtRayStackSlot), ctx->stream));

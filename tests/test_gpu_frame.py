@@ -24,7 +24,7 @@ def _setup(ctx, model, W, H, NR):
     helpers.upload(ctx, model, lights, bn)
     ctx.resize(W, H, NR)
     for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0), (core.OPT_FRAMES_IN_FLIGHT, 2),
-                 (core.OPT_FRAME_TRAIN, 1), (core.OPT_TRAIN_PARTS, 2), (core.OPT_MERGE_PASSES, 1), (core.OPT_SHADOW_STREAM, 2)):
+                 (core.OPT_FRAME_TRAIN, 1), (core.OPT_TRAIN_PARTS, 2), (core.OPT_TRAIN_MAX_MB, 0), (core.OPT_MERGE_PASSES, 1), (core.OPT_SHADOW_STREAM, 2)):
         ctx.set_option(o, v)
     return helpers.oracle_scene(model, lights, bn), oracle.Frame(W, H, NR)
 
@@ -466,6 +466,13 @@ def test_frame_train_equals_sequential(gpu_ctx, oracle_lib, monkey, trav, reseed
     gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
     gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 1 if parts > 1 else 2)      # another number of bands: the ring is rebuilt, its head kept
     gpu_ctx.render_samples(frame, 6); oracle_frames(6); check()
+    # a train that may not have the memory it needs (PT_OPT_TRAIN_MAX_MB; the same path serves a device that is full): the
+    # frames run one per pipe, from the RNG states the train left, and the train picks up again when it may
+    gpu_ctx.set_option(core.OPT_TRAIN_MAX_MB, 1)
+    gpu_ctx.render_samples(frame, 5); oracle_frames(5); check()
+    gpu_ctx.render_sample(frame); oracle_frames(1); check()
+    gpu_ctx.set_option(core.OPT_TRAIN_MAX_MB, 0)
+    gpu_ctx.render_samples(frame, 5); oracle_frames(5); check()
     # a cleared accumulation reseeds exactly the first frame of the next call (launch.comp:49-50)
     gpu_ctx.clear_accumulation(); fr.clear_accumulation()
     gpu_ctx.render_samples(frame, 3); oracle_frames(3); check()
