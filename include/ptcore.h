@@ -285,7 +285,9 @@ enum {
                                     half the launches, one stream per frame, and a frame rate that no longer hinges on the
                                     number of hardware queues; needs traversal 1 or 2 on 64 B or 48 B records, otherwise the
                                     passes stay apart.  Results do not depend on it */
-    PT_OPT_FRAME_TRAIN    = 14,  /* pt_render_sample[s]: 1 (default) = the frames of a call advance together, one bounce per step:
+    PT_OPT_FRAME_TRAIN    = 14,  /* pt_render_sample[s]: 0 = never, 1 = wherever it can serve, 2 (default) = where it can serve and
+                                    numRays >= 3 (with one bounce three frames in flight do as well).  The frame train: the
+                                    frames of a call advance together, one bounce per step:
                                     a step is one launch pass (the frame that enters), one traversal launch over the
                                     closest-hit rays of every frame in flight and the shadow rays of the step before, one
                                     resolve pass (the frame that leaves) and one shade pass, all on the context's stream;

@@ -12,21 +12,26 @@ ap.add_argument("--frames", type=int, default=120)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--layout", type=int, default=0)
+ap.add_argument("--slots", default="8")
 ap.add_argument("--bits", type=int, default=4)
 lists = ("train", "parts", "merge", "blocks", "refill", "inflight")
 defaults = dict(train="1", parts="2", merge="1", blocks="0", refill="0", inflight="3")
 for name in lists:
     ap.add_argument("--" + name, default=defaults[name])
 args = ap.parse_args()
-if args.scene == "sanmiguel":
+if args.scene == "bunny":
+    import numpy as np
+    pos, aux, idx = pt.load_ply(os.path.join(ROOT, "tests", "golden", "models", "CBbunny.ply"))
+    cam = dict(orbit_angle=-np.pi / 2, orbit_height=0.75, focus_center=(0.0, 0.75, 0.0))
+elif args.scene == "sanmiguel":
     pos, aux, idx = pt.scenes.san_miguel_like(); cam = dict(pt.scenes.COURTYARD_CAMERA)
 else:
     pos, aux, idx = pt.scenes.sponza_like(); cam = dict(pt.scenes.SPONZA_CAMERA)
 nodes, ridx, _ = pt.build_bvh(pos, idx, 16)
-W, H, NR = args.width, args.height, 8
+W, H = args.width, args.height
 print("hardware queues:", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
 grid = [[int(v) for v in getattr(args, name).split(",")] for name in lists]
-for trav in [int(v) for v in args.traversal.split(",")]:
+for trav, NR in itertools.product([int(v) for v in args.traversal.split(",")], [int(v) for v in args.slots.split(",")]):
     for train, parts, merge, blocks, refill, inflight in itertools.product(*grid):
         ctx = pt.PathTracer(0)
         ctx.set_option(core.OPT_RECORD_LAYOUT, args.layout)
@@ -42,6 +47,6 @@ for trav in [int(v) for v in args.traversal.split(",")]:
         t = time.perf_counter()
         ctx.render_samples(100, args.frames); ctx.synchronize()
         dt = time.perf_counter() - t
-        print(f"{args.scene} {W}x{H} traversal {trav} train {train} parts {parts} merge {merge} blocks {blocks} refill {refill} in flight {inflight}: "
+        print(f"{args.scene} {W}x{H} slots {NR} traversal {trav} train {train} parts {parts} merge {merge} blocks {blocks} refill {refill} in flight {inflight}: "
               f"{args.frames / dt:.1f} spp/s ({args.frames} frames in {args.frames + NR if train else args.frames} steps)", flush=True)
         ctx.close()

@@ -51,8 +51,10 @@ ctx.render_samples(1, 9)
 ctx.synchronize()
 t = time.perf_counter()
 ctx.render_samples(20, args.frames)
+tq = time.perf_counter() - t
 ctx.synchronize()
 dt = time.perf_counter() - t
+print(f"host returned after {tq*1e3:.1f} ms of {dt*1e3:.1f} ms")
 rc = ctx.render_sample(20 + args.frames, want_ray_counts=True)
 rays = int(rc[:2 * NR].sum())
 print(f"{args.scene} {W}x{H} slots {NR} traversal {args.traversal} in flight {args.inflight} blocks {args.blocks} refill {args.refill} reseed {args.reseed} shadow stream {args.shadow_stream} merge {args.merge}: {args.frames/dt:.2f} spp/s, {dt/args.frames*1e3:.2f} ms/frame, rays/sample {rays}, {rays*args.frames/dt/1e6:.0f} Mrays/s")
