@@ -403,17 +403,19 @@ __global__ __launch_bounds__(256) void k_resolve(FrameArgs f)
     const uint32_t pix = f.row0 * f.W + blockIdx.x * 256 + threadIdx.x;
     if (pix >= f.row1 * f.W) return;
     const PtRayStackSlot* s = f.stack + (size_t)pix * f.c.numRays;
+    /* composite.frag walks the slots from the deepest to the first and starts over from zero at every slot whose prob is not
+       positive: what comes out depends on the slots before the first such slot only.  Most paths end after two or three
+       bounces, so finding that slot first and walking back from it reads a third of the stack's lines */
+    int end = (int)f.c.numRays;
+    for (int depth = 0; depth < (int)f.c.numRays; depth++)
+        if (!((float)hi16(((const uint32_t*)(s + depth))[11]) > 0.0f)) { end = depth; break; }
     float L[3] = { 0, 0, 0 };
-    for (int depth = (int)f.c.numRays - 1; depth >= 0; depth--) {
+    for (int depth = end - 1; depth >= 0; depth--) {
         uint4 q = ((const uint4*)(s + depth))[2];
         float prob = (float)hi16(q.w);
-        if (prob > 0.0f) {
-            float w[3] = { (float)lo16(q.z), (float)hi16(q.z), (float)lo16(q.w) };
-            float al[3] = { (float)lo16(q.x), (float)hi16(q.x), (float)lo16(q.y) };
-            for (int k = 0; k < 3; k++) { L[k] *= prob; L[k] += w[k]; L[k] *= al[k]; }
-        } else {
-            L[0] = L[1] = L[2] = 0.0f;
-        }
+        float w[3] = { (float)lo16(q.z), (float)hi16(q.z), (float)lo16(q.w) };
+        float al[3] = { (float)lo16(q.x), (float)hi16(q.x), (float)lo16(q.y) };
+        for (int k = 0; k < 3; k++) { L[k] *= prob; L[k] += w[k]; L[k] *= al[k]; }
     }
     uint2 cur;
     cur.x = (uint32_t)hbits((h16)L[0]) | ((uint32_t)hbits((h16)L[1]) << 16);
