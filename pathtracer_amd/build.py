@@ -24,6 +24,8 @@ def needs_build():
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
+        if not os.path.exists(os.path.join(os.path.dirname(HERE), "examples", "pt_host")):
+            build_example(verbose)
         return LIB
     objs = []
     for src in SOURCES:
@@ -40,7 +42,21 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    build_example(verbose)
     return LIB
+
+
+def build_example(verbose=True):
+    """examples/pt_host: the C++ host above the C ABI (host code only; links the library just built)."""
+    ex = os.path.join(os.path.dirname(HERE), "examples")
+    src = os.path.join(ex, "pt_host.cpp")
+    if not os.path.exists(src):
+        return
+    cmd = [HIPCC, "-x", "c++", "-O2", "-std=c++17", "-Wall", src, "-o", os.path.join(ex, "pt_host"), "-L" + HERE, "-lptcore",
+           "-Wl,-rpath,$ORIGIN/../pathtracer_amd"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
 
 
 if __name__ == "__main__":
