@@ -373,7 +373,7 @@ def test_frames_in_flight_equal_sequential(gpu_ctx, oracle_lib, monkey, in_fligh
     gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
 
 
-@pytest.mark.parametrize("shape", [(100, 50, 3, 3), (70, 44, 2, 4), (33, 9, 5, 5)])
+@pytest.mark.parametrize("shape", [(100, 50, 3, 3), (70, 44, 2, 4), (33, 9, 5, 5), (64, 40, 1, 2), (48, 24, 12, 12)])
 def test_frame_train_odd_shapes(gpu_ctx, monkey, shape):
     """Widths that are no multiple of the launch pass's 32 x 8 tiles, heights that do not split into equal bands (or are too
     small for the bands asked for), fewer bounces than slots: the train's accumulation, current image and per-depth ray
