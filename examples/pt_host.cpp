@@ -1,7 +1,7 @@
 /*
  * pt_host.cpp - a C++ host above the C ABI of include/ptcore.h, in the shape of the reference's own host:
  * what PathTracer.cpp does between loading a model and presenting a frame, with every Vulkan object and dispatch
- * replaced by the library call that INTEGRATION.md names for it.  No Python, no torch: the program links
+ * replaced by the library call that stands in for it (table below).  No Python, no torch: the program links
  * libptcore.so and nothing else.
  *
  *   reference (PathTracer.cpp)                                      here
