@@ -245,29 +245,37 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pos, aux, ridx, nodes, d_rays, args.cpu_seconds)
-    certified = None
-    if rank == 0 and world == 1 and not args.no_extra:
+    extra = {}
+
+    def extra_item(name, fn):
+        """One context number; a failure is reported under the item's own name and leaves the headline and the other items alone."""
         try:
-            certified = certified_walk(ctx, d_rays, d_hits, n, trav)
-        except Exception as e:          # the context lines must not take the headline down
-            certified = {"error": str(e)}
+            extra[name] = fn()
+        except Exception as e:
+            extra[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    single = rank == 0 and world == 1 and not args.no_extra
+    if single:
+        extra_item("certified_walk", lambda: certified_walk(ctx, d_rays, d_hits, n, trav))
+        extra_item("any_hit", lambda: any_hit_walk(ctx, d_rays, d_hits, n))
     d_rays.free(); d_hits.free()
-    if rank == 0 and world == 1 and not args.no_extra:
-        try:
-            result["extra"] = {"certified_walk": certified, "san_miguel_stand_in": path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0])}
-            result["extra"]["san_miguel_stand_in_4k"] = path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 48)
-            result["extra"]["san_miguel_stand_in_certified_frames"] = certified_frames(ctx, ridx.shape[0], nodes.shape[0])
+    if single:
+        extra_item("san_miguel_stand_in", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0]))
+        extra_item("san_miguel_stand_in_4k", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 48))
+        extra_item("san_miguel_stand_in_certified_frames", lambda: certified_frames(ctx, ridx.shape[0], nodes.shape[0]))
+
+        def sponza():
             spos, saux, sidx = pt.scenes.sponza_like()
             snodes, sridx, _ = pt.build_bvh(spos, sidx, threads)
             ctx.upload_scene(spos, saux, sridx, snodes, pt.default_lights(), pt.load_blue_noise())
-            result["extra"]["sponza_stand_in"] = path_tracer_spp(ctx, sridx.shape[0], snodes.shape[0], camera=pt.scenes.SPONZA_CAMERA)
-        except Exception as e:      # the context lines must not take the headline down
-            result["extra"] = {"error": str(e)}
+            return path_tracer_spp(ctx, sridx.shape[0], snodes.shape[0], camera=pt.scenes.SPONZA_CAMERA)
+        extra_item("sponza_stand_in", sponza)
+        result["extra"] = extra
     if world > 1 and not args.no_extra:
-        extra = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend)
-        extra4k = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend, 3840, 2160, 32)
+        part = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend)
+        part4k = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend, 3840, 2160, 32)
         if rank == 0:
-            result["extra"] = {"san_miguel_stand_in_partitioned": extra, "san_miguel_stand_in_partitioned_4k": extra4k}
+            result["extra"] = {"san_miguel_stand_in_partitioned": part, "san_miguel_stand_in_partitioned_4k": part4k}
     ctx.close()
     if world > 1:
         dist.barrier()
@@ -359,6 +367,22 @@ def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
     return {"Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
             "rays_whose_hit_differs_from_the_reference_order_walk": differ_ref,
             "rays_whose_hit_differs_in_the_headline_walk": differ_fast, "rays": n}
+
+
+def any_hit_walk(ctx, d_rays, d_hits, n, steps=5):
+    """Context number: the same ray set as any-hit rays (the walk of the shadow rays, intersections.glsl:73-77 with stopIfHit):
+    a ray ends at the first triangle it hits.  The occluded share must equal the closest-hit walk's hit rate."""
+    import pathtracer_amd as pt
+    ctx.trace_rays_device(d_rays, n, d_hits, any_hit=True)
+    ctx.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        ctx.trace_rays_device(d_rays, n, d_hits, any_hit=True)
+    ctx.synchronize()
+    dt = time.perf_counter() - t
+    m = min(n, 1 << 20)
+    occluded = float((d_hits.to_host(pt.HIT_DT, m)["i1"] >= 0).mean())
+    return {"Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "occluded_share_of_first_2^20": round(occluded, 4), "rays": n}
 
 
 def certified_frames(ctx, num_triangles, num_nodes):

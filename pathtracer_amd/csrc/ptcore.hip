@@ -421,9 +421,9 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
     if (ctx->optSecondWalk == 0)
         return launch_trace<MODE, false>(ctx, b, count, stream, area, fixed);    /* traversal 3 maps to the reference-order walk there */
     /* the listed rays are few and their walks long: one wavefront per ray (k_trace_ref_wave); no stack, no spill area */
-    dim3 grid2(ctx->numCUs * 2);
-    if (count) hipLaunchKernelGGL((k_trace_ref_wave<MODE, true>), grid2, block, 0, stream, b);
-    else hipLaunchKernelGGL((k_trace_ref_wave<MODE, false>), grid2, block, 0, stream, b);
+    dim3 grid2(ctx->numCUs * 8), block2(64);        /* one wavefront per workgroup */
+    if (count) hipLaunchKernelGGL((k_trace_ref_wave<MODE, true>), grid2, block2, 0, stream, b);
+    else hipLaunchKernelGGL((k_trace_ref_wave<MODE, false>), grid2, block2, 0, stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -443,7 +443,8 @@ int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area
     TraceArgs b = a;
     b.order = flag; b.countPtr = ctr; b.countPtr2 = nullptr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
     if (ctx->optSecondWalk == 0) return launch_trace<MODE_JOBS, false>(ctx, b, false, stream, area);
-    hipLaunchKernelGGL((k_trace_ref_wave<MODE_JOBS, false>), dim3(ctx->numCUs * 2), block, 0, stream, b);
+    /* one wavefront per workgroup: these find room beside a launch that fills the CUs more easily than groups of four */
+    hipLaunchKernelGGL((k_trace_ref_wave<MODE_JOBS, false>), dim3(ctx->numCUs * 8), dim3(64), 0, stream, b);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64) void k_trace_ref_speculative_shadow(TraceArgs a
  * window the next 64 nodes are fetched from where it went.  Node for node this is the loop of intersections.glsl:64-111
  * with the arithmetic of k_trace_ref; closest hit only, rays from a.order (the list) or in batch order. */
 template <int MODE, bool COUNT>      /* MODE_RAYS or MODE_JOBS */
-__global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)      /* any whole number of wavefronts per workgroup up to four */
 {
     const int lane = threadIdx.x & 63;
     const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
@@ -398,8 +398,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)
     /* these few wavefronts are what a whole pass waits for, usually beside another launch that fills the CUs: they go first
        wherever the hardware lets a wavefront's priority decide (second walk of a frame-train step 2.2 -> 0.9 ms) */
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t numWaves = gridDim.x * PT_WAVES_PER_BLOCK;
-    const uint32_t firstRay = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * PT_WAVES_PER_BLOCK + (threadIdx.x >> 6)));
+    const uint32_t wavesPerBlock = blockDim.x >> 6;       /* launched with one to four wavefronts per workgroup */
+    const uint32_t numWaves = gridDim.x * wavesPerBlock;
+    const uint32_t firstRay = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)));
     for (uint64_t k = firstRay; k < total; k += numWaves) {
         const uint64_t id = a.order ? (uint64_t)a.order[k] : k;
         RayRegs r; uint32_t exclude = 0, tag = 0;
