@@ -320,7 +320,9 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value);
  * 1,2,3,4,7,8 of PathTracer.cpp:490-502).  Host pointers are borrowed for the call only.
  * `nodes` is the reference-layout array; the flattening pass runs inside and first checks that the
  * array is a pre-order tree with consistent skip links and one leaf per triangle (a malformed array is
- * refused with -1 and a reason: a walk over it would not end), and that every vertex index is in range. */
+ * refused with -1 and a reason: a walk over it would not end), and that every vertex index is in range.
+ * The traversal records of a scene live in one buffer addressed with unsigned 32-bit byte offsets: 64 B x (2T - 1)
+ * must stay below 4 GiB, that is T <= 33.5 million triangles (-1 beyond). */
 PT_API int pt_scene_upload(PtContext* ctx,
                            const float* positions, uint32_t num_vertices,
                            const PtVertexAux* aux,

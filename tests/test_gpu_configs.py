@@ -205,3 +205,46 @@ def test_treelet_layout_equals_two_box_layout_at_scale(san_miguel):
             a, b = out[(core.LAYOUT_RECORDS64, trav, any_hit)], out[(core.LAYOUT_TREELETS, trav, any_hit)]
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"traversal {trav}, any_hit {any_hit}: {int((a != b).sum())} hits differ"
             assert 0.5 < (a["i1"] >= 0).mean() < 0.95
+
+
+def test_scene_past_two_gib_of_records(oracle_lib):
+    """A 21 M-triangle scene: 2.7 GB of traversal records, past the point where a signed 32-bit byte offset or buffer size
+    would wrap (the record buffer is addressed through one 4 GB buffer descriptor with unsigned 32-bit offsets; uploads past
+    that are refused).  The reference-order and certified walks equal the oracle's walk over the same tree bit for bit on a
+    sample of rays, the near-first walk within its bar, and on 2^22 rays on the device the certified walk equals the
+    reference-order walk; the treelet layout agrees as well."""
+    pos, aux, idx = pt.scenes.courtyard(21_000_000, seed=17)
+    model = _model(pos, aux, idx)
+    T = model["indices"].shape[0]
+    assert 64 * (2 * T - 1) > (1 << 31)
+    lo, hi = model["nodes"][0]["a"], model["nodes"][0]["b"]
+    rays = helpers.random_rays(lo, hi, 30_000, seed=5)
+    osc = helpers.oracle_scene(model)
+    want = osc.trace(rays)
+    n = 1 << 22
+    dev = {}
+    for layout in (core.LAYOUT_RECORDS64, core.LAYOUT_TREELETS):
+        c = pt.PathTracer(0)
+        try:
+            c.set_option(core.OPT_RECORD_LAYOUT, layout)
+            helpers.upload(c, model)
+            for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED, core.TRAVERSAL_FLAT_ORDERED):
+                c.set_option(core.OPT_TRAVERSAL, trav)
+                got = c.trace_rays(rays)
+                if trav == core.TRAVERSAL_FLAT_ORDERED:
+                    assert (got["i1"] != want["i1"]).mean() <= 1e-4
+                else:
+                    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), f"layout {layout}, traversal {trav}"
+            d_rays, d_hits = c.alloc(n * 32), c.alloc(n * 16)
+            c.generate_rays(d_rays, n, seed=9)
+            for trav in (core.TRAVERSAL_FLAT, core.TRAVERSAL_CERTIFIED):
+                c.set_option(core.OPT_TRAVERSAL, trav)
+                c.trace_rays_device(d_rays, n, d_hits)
+                dev[(layout, trav)] = d_hits.to_host(pt.HIT_DT, n)
+            d_rays.free(); d_hits.free()
+        finally:
+            c.close()
+    ref = dev[(core.LAYOUT_RECORDS64, core.TRAVERSAL_FLAT)]
+    assert 0.5 < (ref["i1"] >= 0).mean() < 0.99
+    for key, got in dev.items():
+        assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), f"{key} differs from the reference-order walk on 64 B records"
