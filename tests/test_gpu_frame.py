@@ -754,3 +754,46 @@ def test_cpp_host_renders_what_the_python_host_renders(gpu_ctx, bunny, tmp_path)
         h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert f"{h:016x}" == hashes["sites"]
     gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+
+
+def test_frame_train_random_configurations(bunny, monkey):
+    """Randomised differential test (fixed seed; scripts/exp_fuzz_frames.py is the long-running twin): random image sizes,
+    path depths, slot counts, traversals, record layouts, reseeding, numbers of bands and sequences of call lengths with a clear
+    in between - the frame train leaves the accumulation, the current image, the per-depth ray counts and the live part of the
+    ray stack that the per-frame pipeline leaves for the same calls."""
+    rng = np.random.default_rng(20261111)
+    for case in range(24):
+        model = (bunny, monkey)[int(rng.integers(2))]
+        W, H = int(rng.integers(8, 200)), int(rng.integers(8, 120))
+        slots = int(rng.integers(1, 10)); NR = int(rng.integers(1, slots + 1))
+        trav = int(rng.choice([1, 2, 3])); layout = int(rng.choice([0, 0, 1])); reseed = int(rng.integers(2)); parts = int(rng.integers(1, 5))
+        calls = [int(v) for v in rng.integers(1, 2 * NR + 4, size=int(rng.integers(1, 5)))]
+        in_flight = int(rng.integers(1, 5))
+        desc = f"case {case}: {W}x{H} slots {slots} numRays {NR} traversal {trav} layout {layout} reseed {reseed} bands {parts} calls {calls}"
+        out = {}
+        for train in (1, 0):
+            ctx = pt.PathTracer(0)
+            try:
+                ctx.set_option(core.OPT_RECORD_LAYOUT, layout)
+                helpers.upload(ctx, model, pt.default_lights(), pt.load_blue_noise())
+                ctx.resize(W, H, slots)
+                for o, v in ((core.OPT_TRAVERSAL, trav), (core.OPT_RESEED, reseed), (core.OPT_FRAME_TRAIN, train), (core.OPT_TRAIN_PARTS, parts),
+                             (core.OPT_FRAMES_IN_FLIGHT, in_flight)):
+                    ctx.set_option(o, v)
+                ctx.set_constants(_consts(model, W, H, NR, 1, BUNNY_CAM))
+                frame, rcs = 1, []
+                for k, n in enumerate(calls):
+                    rcs.append(ctx.render_samples(frame, n, want_ray_counts=True)[:2 * NR].copy()); frame += n
+                    if k == 1:
+                        ctx.clear_accumulation()           # the next call's first frame reseeds from its jitter
+                stack, _ = ctx.readback_raystack()
+                out[train] = (ctx.readback_accumulation(), ctx.readback_current(), np.concatenate(rcs),
+                              stack[:W * H * NR].reshape(W * H, NR))          # a pixel's slots lie numRays apart
+            finally:
+                ctx.close()
+        a, b = out[1], out[0]
+        for k, what in enumerate(("accumulation", "current image", "ray counts")):
+            assert np.array_equal(np.asarray(a[k]).view(np.uint8), np.asarray(b[k]).view(np.uint8)), f"{desc}: {what} differs"
+        prob = b[3]["prob"].view(np.float16).astype(np.float32)
+        live = np.cumprod(np.concatenate([np.ones((prob.shape[0], 1), bool), prob[:, :-1] > 0], axis=1), axis=1).astype(bool) & (prob > 0)
+        assert np.array_equal(a[3][live].view(np.uint8), b[3][live].view(np.uint8)), f"{desc}: ray stack differs in a live slot"
