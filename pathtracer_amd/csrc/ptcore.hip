@@ -1095,6 +1095,9 @@ static int train_render(PtContext* ctx, uint32_t first_frame_index, uint32_t num
     const uint32_t head0 = t.head;
     auto pos_of = [&](uint32_t i) { return (head0 + 1u + i) % t.F; };
     const bool seedFirst = ctx->accumEmpty;
+    const bool certified = ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest;
+    if (certified)          /* the list of jobs for the second walk: allocated before anything is queued */
+        for (int k = 0; k < t.parts; k++) if (!t.part[k].dFlag) HIPCHK(hipMalloc((void**)&t.part[k].dFlag, t.part[k].cap * 4));
 
     FrameArgs f; fill_frame_args(ctx, ctx->pipe[0], f);
     f.rayCounts = t.dRayCounts; f.fuseCompact = 1;
@@ -1127,8 +1130,7 @@ static int train_render(PtContext* ctx, uint32_t first_frame_index, uint32_t num
                 a.stack = t.dRing; a.hitRecs = p.dHitRecs;
                 a.jobs = p.dJobs[cur]; a.countPtr = p.dCtr + TC_NJOBS; a.fetchCounter = p.dCtr + TC_FETCH;
                 a.shadowRays = p.dShadow[q]; a.countPtr2 = p.dCtr + TC_NSHADOW + q;
-                if (ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest) {
-                    if (!p.dFlag) HIPCHK(hipMalloc((void**)&p.dFlag, p.cap * 4));
+                if (certified) {
                     if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG)) return rc;
                 } else if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
             }
