@@ -173,7 +173,7 @@ def main():
 
     # HBM-side bytes per launch come from separate rocprofv3 --pmc passes of this same command (bench.py cannot
     # collect counters on itself); profiles/traffic.json holds the latest, keyed by workload and record layout
-    traffic, l2_hit, traffic_src = None, None, None
+    traffic, l2_hit, traffic_src, valu_busy = None, None, None, None
     trav = args.traversal if args.traversal >= 0 else ctx.get_option(core.OPT_TRAVERSAL)
     layout = ctx.get_option(core.OPT_RECORD_LAYOUT)
     try:
@@ -182,6 +182,7 @@ def main():
             if (k["triangles"] == int(ridx.shape[0]) and k["rays_per_gpu"] == n and k["traversal"] == trav
                     and k.get("record_layout", 0) == layout):
                 traffic, l2_hit, traffic_src = rec["traffic_bytes_per_launch"], rec.get("l2_hit_rate"), rec.get("source")
+                valu_busy = rec.get("valu_busy")
     except (OSError, KeyError, ValueError):
         pass
     # the roofline figure is what crosses the fabric per unit of kernel time; the bytes the walk asks for (most of
@@ -230,6 +231,7 @@ def main():
             "traffic": traffic,
             "traffic_source": traffic_src,
             "l2_hit_rate": l2_hit,
+            "valu_busy": valu_busy,
             "requested_GBps": round(requested, 1),
             "kernel": f"{kernel_name} (closest hit)",
             "kernel_ms": round(kernel_ms, 3),
