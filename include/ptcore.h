@@ -283,8 +283,8 @@ enum {
     PT_OPT_MERGE_PASSES   = 13,  /* inside pt_render_sample[s]: 1 (default) = the shadow rays of bounce d are traced by the same
                                     launch as the closest-hit rays of bounce d + 1 (both wait for the shade pass of d only):
                                     half the launches, one stream per frame, and a frame rate that no longer hinges on the
-                                    number of hardware queues; needs traversal 1 or 2 on 64 B or 48 B records, otherwise the
-                                    passes stay apart.  Results do not depend on it */
+                                    number of hardware queues; needs traversal 1 or 2, otherwise the passes stay apart.
+                                    Results do not depend on it */
     PT_OPT_FRAME_TRAIN    = 14,  /* pt_render_sample[s]: 0 = never, 1 = wherever it can serve, 2 (default) = where it can serve and
                                     numRays >= 3 (with one bounce three frames in flight do as well).  The frame train: the
                                     frames of a call advance together, one bounce per step:
@@ -292,9 +292,10 @@ enum {
                                     closest-hit rays of every frame in flight and the shadow rays of the step before, one
                                     resolve pass (the frame that leaves) and one shade pass, all on the context's stream;
                                     numRays + 1 ray stacks are kept in a ring (48 B x W x H x slots each) and a call of N
-                                    frames takes N + numRays steps.  Serves traversals 1, 2 and 3 on 64 B records (1 and 2
-                                    on 48 B records); otherwise, and with 0, frames run one per pipe
-                                    (PT_OPT_FRAMES_IN_FLIGHT).  Every buffer comes out the same byte for byte */
+                                    frames takes N + numRays steps.  Serves traversals 1, 2 and 3 on every record layout
+                                    (3 walks 48 B records in reference order); traversal 0, the stale-slot option and the
+                                    voting build run one frame per pipe (PT_OPT_FRAMES_IN_FLIGHT), as does 0 here.  Every
+                                    buffer comes out the same byte for byte */
     PT_OPT_TRAIN_PARTS    = 15,  /* 1..4 (default 2): the frame train renders the image in this many bands of rows, each a train
                                     of its own on its own stream (a pixel's path never leaves its band): while one band's
                                     shade, launch and resolve passes run, another band's traversal launch has the GPU */

@@ -380,7 +380,10 @@ int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, boo
     dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : (train ? 6 : 4))), block(PT_BLOCK);     /* the train's launches are batch-sized */
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
     const bool ordered = ctx->optTraversal == 2;      /* 3 comes here where the certified walk is not to be had: reference order */
-    if (ctx->compact) {
+    if (ctx->dTreelets) {
+        if (ordered) hipLaunchKernelGGL((k_trace_tree<MODE_MIXED, false, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_tree<MODE_MIXED, false, false, false>), grid, block, 0, stream, a);
+    } else if (ctx->compact) {
         if (ordered) hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, true, false, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, false, false, true>), grid, block, 0, stream, a);
     } else {
@@ -906,7 +909,7 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
     };
     /* merged passes: this bounce's shadow rays wait for the next bounce's closest-hit launch, unless there is none, or that
        launch is one of the kinds that cannot take them (certified walk, treelets, the reference layout) */
-    const bool mergeable = ctx->optMergePasses && (ctx->optTraversal == 1 || ctx->optTraversal == 2) && !ctx->dTreelets;
+    const bool mergeable = ctx->optMergePasses && (ctx->optTraversal == 1 || ctx->optTraversal == 2);
     if (overlapped && mergeable && !speculative && depth + 1 < ctx->consts.numRays) {
         p.deferredShadow = (int)depth;
         return 0;
@@ -1191,8 +1194,7 @@ try {
     /* (2 = auto, the default: the train where paths are deep enough for it to pay.  With one bounce the per-frame pipeline's
        three frames in flight do as well or better: 1 309 against 1 197 spp/s on the bunny, 289 against 305 on 5.8 M triangles) */
     const bool wantTrain = ctx->optFrameTrain == 1 || (ctx->optFrameTrain == 2 && ctx->consts.numRays >= 3);
-    if (wantTrain && !ctx->optStale && !speculative_depth0 && ctx->optTraversal != 0 && !ctx->dTreelets &&
-        ctx->consts.numRays <= PT_MAX_TRAIN_DEPTH) {
+    if (wantTrain && !ctx->optStale && !speculative_depth0 && ctx->optTraversal != 0 && ctx->consts.numRays <= PT_MAX_TRAIN_DEPTH) {
         const uint32_t want = num_frames < ctx->consts.numRays + 1 ? num_frames : ctx->consts.numRays + 1;
         const int rc = ensure_train(ctx, want, ctx->optTrainParts);
         if (rc < 0) return rc;

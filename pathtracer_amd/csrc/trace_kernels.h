@@ -772,12 +772,14 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
-    const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
+    const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.treelets, 0, (int)a.treeletBytes, 0x00020000);
     const uint32_t NO_GATE = 0xFC00u;                                   /* -inf: max_t > -inf always holds */
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
     bool active = false, pend = false;
+    bool shadowLane = MODE == MODE_SHADOW, freshShadow = false;      /* MODE_MIXED: what kind of ray the lane walks / has just loaded */
     uint32_t pendIdx = 0;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
@@ -790,15 +792,27 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
     const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
 
+    /* the three places where a mixed launch has to ask what kind of ray a lane holds (as in k_trace_flat) */
+    auto issue = [&](uint64_t rid, RayWords& w) -> bool {
+        if (MODE != MODE_MIXED) return issue_ray<MODE>(a, rid, w);
+        freshShadow = rid >= numJobs;
+        return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
+    };
+    auto store = [&](bool h, float t, int32_t s1, int32_t s2, int32_t s3, float al, float be, float ga, uint32_t orig) {
+        if (MODE != MODE_MIXED) store_result<MODE>(a, id, tag, h, t, s1, s2, s3, al, be, ga, orig);
+        else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, t, s1, s2, s3, al, be, ga, orig);
+        else store_result<MODE_JOBS>(a, id, tag, h, t, s1, s2, s3, al, be, ga, orig);
+    };
     auto start_ray = [&](const RayWords& w) {
-        finish_ray<MODE>(w, r, exclude, tag);
+        if (MODE != MODE_MIXED) finish_ray<MODE>(w, r, exclude, tag);
+        else { shadowLane = freshShadow; if (shadowLane) finish_ray<MODE_SHADOW>(w, r, exclude, tag); else finish_ray<MODE_JOBS>(w, r, exclude, tag); }
         if (COUNT) { nRay++; nBox++; }
         hit = false; ranOff = false; sp = 0;
         rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
         float ftmin;
         bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
         if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
-        else store_result<MODE>(a, id, tag, false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
+        else store(false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
     };
     auto push = [&](uint32_t ref, uint32_t gates) {
         if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = ref; sGate[wave][sp][lane] = gates; }
@@ -813,12 +827,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
         if (nIdle == 64 && pool.exhausted()) break;
         bool fresh = false;
         RayWords w;
-        if (MODE != MODE_SHADOW && pend) { id = pendIdx; pend = false; fresh = issue_ray<MODE>(a, id, w); }
+        if (MODE != MODE_SHADOW && pend) { id = pendIdx; pend = false; fresh = issue(id, w); }
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
             if (canTake && nid != ~0ull) {
                 if (MODE != MODE_SHADOW && a.order) { pendIdx = a.order[nid]; pend = true; }
-                else { id = nid; fresh = issue_ray<MODE>(a, id, w); }
+                else { id = nid; fresh = issue(id, w); }
             }
         }
 
@@ -855,8 +869,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
                     r.max_t = t; alpha = al; beta = be; gamma = ga;
                     hit = true;
                     if (MODE != MODE_SHADOW) { hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w; }
-                    if (MODE == MODE_JOBS) hitLeaf = leafId;
-                    if (ANYHIT) { done = true; needPop = false; }
+                    if (MODE == MODE_JOBS || MODE == MODE_MIXED) hitLeaf = leafId;
+                    if (ANYHIT || (MODE == MODE_MIXED && shadowLane)) { done = true; needPop = false; }
                 }
             }
         } else {
@@ -930,8 +944,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
 
         if (done) {
             uint32_t orig = 0u;
-            if (MODE == MODE_JOBS && ranOff && hit) orig = hitLeaf;
-            store_result<MODE>(a, id, tag, hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
+            if ((MODE == MODE_JOBS || (MODE == MODE_MIXED && !shadowLane)) && ranOff && hit) orig = hitLeaf;
+            store(hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
             active = false;
         }
         }   /* if (active) */
