@@ -1160,11 +1160,13 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             const h16x2 ax = as_h2(q1.z), ay = as_h2(q1.w), az = as_h2(q2.x), bx = as_h2(q2.y), by = as_h2(q2.z), bz = as_h2(q2.w);
             box_pair(r, rx, ry, rz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR);
             const f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
-            float boundL, boundR;
-            /* (skipping the bounds in wavefronts that hold shadow rays only, by a vote, was measured: 133 against 157 spp/s,
-               because the kernel then takes 90 registers instead of 83: five of its wavefronts per SIMD then leave 32
-               registers free instead of 72, and the second walk's wavefronts, which need 64, no longer fit beside them) */
-            entry_bound(dx, dy, dz, invx, invy, invz, ax, ay, az, bx, by, bz, boundL, boundR);
+            float boundL = 0.0f, boundR = 0.0f;
+            /* Shadow rays cull with the reference's test and never use the bounds.  A per-lane branch lets a wavefront
+             * whose lanes all hold shadow rays jump over the arithmetic and keeps the kernel at 83 VGPRs; a wave-wide
+             * vote around the same call took 90, which left no room for the second walk's wavefronts beside this
+             * launch (133 against 157 spp/s on certified frames). */
+            if (!(MODE == MODE_MIXED && shadowLane))
+                entry_bound(dx, dy, dz, invx, invy, invz, ax, ay, az, bx, by, bz, boundL, boundR);
             /* enter unless the order-independent part of the reference's verdict fails or the box certainly begins beyond
                everything that still matters */
             const float reach = fmaxf(r.max_t, hitGate);
