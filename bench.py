@@ -262,8 +262,8 @@ def main():
         extra_item("any_hit", lambda: any_hit_walk(ctx, d_rays, d_hits, n))
     d_rays.free(); d_hits.free()
     if single:
-        extra_item("san_miguel_stand_in", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0]))
-        extra_item("san_miguel_stand_in_4k", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 48))
+        extra_item("san_miguel_stand_in", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], per_call=True))
+        extra_item("san_miguel_stand_in_4k", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 96))
         extra_item("san_miguel_stand_in_certified_frames", lambda: certified_frames(ctx, ridx.shape[0], nodes.shape[0]))
 
         def sponza():
@@ -272,6 +272,15 @@ def main():
             ctx.upload_scene(spos, saux, sridx, snodes, pt.default_lights(), pt.load_blue_noise())
             return path_tracer_spp(ctx, sridx.shape[0], snodes.shape[0], camera=pt.scenes.SPONZA_CAMERA)
         extra_item("sponza_stand_in", sponza)
+
+        def bunny():
+            # BASELINE configs[1]: the reference's own model, primary + one diffuse bounce (numRays = 2), shadow rays included
+            bpos, baux, bidx = pt.load_ply(os.path.join(ROOT, "tests", "golden", "models", "CBbunny.ply"))
+            bnodes, bridx, _ = pt.build_bvh(bpos, bidx, threads)
+            ctx.upload_scene(bpos, baux, bridx, bnodes, pt.default_lights(), pt.load_blue_noise())
+            cam = dict(orbit_angle=-np.pi / 2, orbit_height=0.75, focus_center=(0.0, 0.75, 0.0))
+            return path_tracer_spp(ctx, bridx.shape[0], bnodes.shape[0], nf=600, camera=cam, NR=2)
+        extra_item("cb_bunny_primary_plus_one_bounce", bunny)
         result["extra"] = extra
     if world > 1 and not args.no_extra:
         part = path_tracer_spp_partitioned(ctx, ridx.shape[0], nodes.shape[0], rank, world, backend)
@@ -392,7 +401,7 @@ def certified_frames(ctx, num_triangles, num_nodes):
     six frames from a cleared buffer is, byte for byte, that of the reference-order walk (= 1) and of the default (= 2)."""
     import pathtracer_amd as pt
     from pathtracer_amd import core
-    W, H, NR, nf = 1920, 1080, 8, 120
+    W, H, NR, nf = 1920, 1080, 8, 240
     ctx.resize(W, H, NR)
     ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
     acc = {}
@@ -417,13 +426,12 @@ def certified_frames(ctx, num_triangles, num_nodes):
             "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
 
 
-def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=120, camera=None):
+def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=240, camera=None, NR=8, per_call=False):
     """Context number: samples per pixel per second of the wavefront path tracer at 1080p (or the size given), 8 bounces
     with next-event estimation, on the scene the context holds (BASELINE configs[2] shape), library defaults: one
     pt_render_samples call of nf frames through the frame train, which takes nf + 8 steps (the eight that fill and drain the
-    ring are inside the timed region)."""
+    ring are inside the timed region; paths of fewer than three slots go frame by frame, three frames in flight)."""
     import pathtracer_amd as pt
-    NR = 8
     ctx.resize(W, H, NR)
     ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **(camera or pt.scenes.COURTYARD_CAMERA)))
     ctx.render_samples(1, NR + 1)          # warm-up: brings the ring of ray stacks to its full size
@@ -434,8 +442,25 @@ def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=120, camer
     dt = time.perf_counter() - t
     rc = ctx.render_sample(100 + nf, want_ray_counts=True)
     rays = int(rc[:2 * NR].sum())
-    return {f"spp_per_s_{H}p": round(nf / dt, 2), "frames_timed": nf, "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
-            "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1)}
+    out = {f"spp_per_s_{H}p": round(nf / dt, 2), "frames_timed": nf, "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
+           "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1)}
+    if per_call:
+        # the reference's own calling pattern (one f_onRender per frame, PathTracer.cpp:672): one render call per frame, with
+        # the frame train flushed at the end of every call (library default) and kept between the calls (PT_OPT_TRAIN_KEEP)
+        from pathtracer_amd import core
+        for keep in (0, 1):
+            ctx.set_option(core.OPT_TRAIN_KEEP, keep)
+            ctx.render_samples(1, NR + 1)
+            ctx.render_flush()
+            ctx.synchronize()
+            t = time.perf_counter()
+            for f in range(nf // 2):
+                ctx.render_sample(200 + f)
+            ctx.render_flush()
+            ctx.synchronize()
+            out["spp_per_s_one_frame_per_call" + ("_train_kept" if keep else "")] = round((nf // 2) / (time.perf_counter() - t), 2)
+        ctx.set_option(core.OPT_TRAIN_KEEP, 0)
+    return out
 
 
 def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, backend, W=1920, H=1080, nf=96):

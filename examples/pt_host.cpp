@@ -19,7 +19,10 @@
  * usage: pt_host <model.ply> <blue_noise_u16le.bin> <out dir> [width height bounces frames mode]
  *   mode "sites"   the reference's own loop: one frame at a time through the dispatch sites (default)
  *   mode "batch"   the same frames in one pt_render_samples call
- * Both leave the same accumulation; the program prints its FNV-1a hash so that two runs can be compared.
+ *   mode "kept"    one pt_render_sample call per frame, as f_onRender asks for them, with the frame train kept between
+ *                  the calls (PT_OPT_TRAIN_KEEP): every call is one step of the train, the picture read in between lags
+ *                  numRays frames behind, pt_render_flush finishes what is in flight
+ * All three leave the same accumulation; the program prints its FNV-1a hash so that two runs can be compared.
  */
 #include "../include/ptcore.h"
 
@@ -48,7 +51,7 @@ static uint64_t fnv1a(const void* p, size_t n)
 int main(int argc, char** argv)
 {
     if (argc < 4) {
-        fprintf(stderr, "usage: %s <model.ply> <blue_noise_u16le.bin> <out dir> [width height bounces frames sites|batch]\n", argv[0]);
+        fprintf(stderr, "usage: %s <model.ply> <blue_noise_u16le.bin> <out dir> [width height bounces frames sites|batch|kept]\n", argv[0]);
         return 2;
     }
     const char* modelPath = argv[1];
@@ -57,7 +60,7 @@ int main(int argc, char** argv)
     const uint32_t W = argc > 4 ? (uint32_t)atoi(argv[4]) : 1920, H = argc > 5 ? (uint32_t)atoi(argv[5]) : 1080;
     const uint32_t numRays = argc > 6 ? (uint32_t)atoi(argv[6]) : 5;            /* PathTracer.cpp:96 */
     const uint32_t frames = argc > 7 ? (uint32_t)atoi(argv[7]) : 16;
-    const bool batch = argc > 8 && strcmp(argv[8], "batch") == 0;
+    const bool batch = argc > 8 && strcmp(argv[8], "batch") == 0, kept = argc > 8 && strcmp(argv[8], "kept") == 0;
     char err[256] = "";
 
     /* the model: PathTracer.cpp:246-264 */
@@ -99,6 +102,14 @@ int main(int argc, char** argv)
         pt_fill_constants(&c, W, H, focus, 0.75f, 3.0f, -1.5707964f, 1, T, 1, numRays, (uint32_t)nodes.size(), ambient);
         if (pt_set_constants(ctx, &c)) return fail(ctx, "pt_set_constants");
         if (pt_render_samples(ctx, 1, frames, 0, nullptr)) return fail(ctx, "pt_render_samples");
+    } else if (kept) {
+        if (pt_set_option(ctx, PT_OPT_FRAME_TRAIN, 1) || pt_set_option(ctx, PT_OPT_TRAIN_KEEP, 1)) return fail(ctx, "pt_set_option");
+        for (uint32_t frame = 1; frame <= frames; frame++) {                     /* f_onRender: one frame asked for, whatever is finished shown */
+            pt_fill_constants(&c, W, H, focus, 0.75f, 3.0f, -1.5707964f, 1, T, frame, numRays, (uint32_t)nodes.size(), ambient);
+            if (pt_set_constants(ctx, &c)) return fail(ctx, "pt_set_constants");
+            if (pt_render_sample(ctx, frame, 0, nullptr)) return fail(ctx, "pt_render_sample");
+        }
+        if (pt_render_flush(ctx)) return fail(ctx, "pt_render_flush");
     } else {
         for (uint32_t frame = 1; frame <= frames; frame++) {                     /* f_onRender, PathTracer.cpp:729-838 */
             pt_fill_constants(&c, W, H, focus, 0.75f, 3.0f, -1.5707964f, 1, T, frame, numRays, (uint32_t)nodes.size(), ambient);
@@ -113,7 +124,7 @@ int main(int argc, char** argv)
     }
     if (pt_synchronize(ctx)) return fail(ctx, "pt_synchronize");
     const double renderMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    printf("%u frames of %u x %u x %u bounces (%s): %.1f ms, %.1f spp/s\n", frames, W, H, numRays, batch ? "one pt_render_samples call" : "dispatch sites",
+    printf("%u frames of %u x %u x %u bounces (%s): %.1f ms, %.1f spp/s\n", frames, W, H, numRays, batch ? "one pt_render_samples call" : kept ? "one call per frame, train kept" : "dispatch sites",
            renderMs, frames / renderMs * 1e3);
 
     std::vector<float> acc(4 * (size_t)W * H);

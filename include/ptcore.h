@@ -303,6 +303,19 @@ enum {
                                     ring of ray stacks and its lists (numRays + 1 stacks: 10 GiB at 1080p x 8 slots, 38 GiB
                                     at 4K).  A call whose train would need more - or more than the device has free - renders
                                     frame by frame instead, with the same results */
+    PT_OPT_TRAIN_KEEP     = 17,  /* 0 (default): a pt_render_sample[s] call returns with all its frames finished (a call of N
+                                    frames takes N + numRays steps of the frame train).  1: the train is kept between calls -
+                                    a call of N frames takes N steps and returns with up to numRays frames still in the
+                                    train, which the next call's steps carry further: a host that renders one frame per call
+                                    (PathTracer.cpp:672, one f_onRender per presented image) runs at the rate of one long
+                                    call.  pt_readback_accumulation, pt_readback_current, pt_dump_current, pt_tonemap and
+                                    pt_synchronize then see the frames finished so far (.w of the accumulation counts them):
+                                    the picture lags numRays frames behind the calls.  pt_render_flush finishes the frames
+                                    in flight, and so does every other call first (options, constants other than
+                                    frameIndex, clear, resize, scene upload, the dispatch sites, ray-stack reads, batches,
+                                    the all-reduce, a render call that asks for ray counts), after which every buffer is
+                                    what frame-by-frame rendering leaves, byte for byte.  While frames are in flight, work
+                                    the caller queues on pt_stream is ordered behind the calls above only */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames the per-frame pipeline keeps in flight (PT_OPT_FRAME_TRAIN = 0, and what
                                     the frame train does not serve), each on its own ray stack and stream; results do not
                                     depend on it.  With merged passes three frames are three streams and HIP's default of
@@ -362,6 +375,9 @@ PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculativ
  * With PT_OPT_STALE_SLOTS set the frames run one at a time.  ray_counts receives the sums over the frames. */
 PT_API int pt_render_samples(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames,
                              int speculative_depth0, uint64_t* ray_counts);
+/* Finishes the frames a kept frame train still holds (PT_OPT_TRAIN_KEEP = 1): numRays steps at most, queued like a render
+ * call.  Nothing to do otherwise.  The reference has no counterpart: its frames are finished when f_onRender returns. */
+PT_API int pt_render_flush(PtContext* ctx);
 
 /* Replaces the dump read-back of PathTracer.cpp:848-854 (RGBA16F current image) and adds the
  * linear accumulation (RGBA32F, .w = sample count).  Host destination buffers. */

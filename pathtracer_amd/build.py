@@ -24,7 +24,9 @@ def needs_build():
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
-        if not os.path.exists(os.path.join(os.path.dirname(HERE), "examples", "pt_host")):
+        ex = os.path.join(os.path.dirname(HERE), "examples")
+        exe, src = os.path.join(ex, "pt_host"), os.path.join(ex, "pt_host.cpp")
+        if not os.path.exists(exe) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(exe)):
             build_example(verbose)
         return LIB
     objs = []

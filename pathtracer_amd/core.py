@@ -42,6 +42,7 @@ OPT_SORT_BITS = 10
 OPT_SHADOW_STREAM = 12
 OPT_MERGE_PASSES = 13
 OPT_TRAIN_MAX_MB = 16            # most device memory (MiB) the frame train may take; 0 = no limit
+OPT_TRAIN_KEEP = 17              # 1: the frame train is kept between render calls (frames stay in flight; render_flush finishes them)
 OPT_TRAIN_PARTS = 15             # 1..4: bands of rows the frame train renders side by side
 OPT_FRAME_TRAIN = 14             # pt_render_samples steps its frames together, one traversal launch per step: 0 never, 1 always, 2 = for numRays >= 3 (default)
 OPT_SECOND_WALK = 11            # certified walk's second pass: 0 = a ray per lane, 1 = a ray per wavefront (default)
@@ -109,6 +110,7 @@ def _load():
         "pt_resolve_accumulate": (i32, [vp]),
         "pt_render_sample": (i32, [vp, u32, i32, vp]),
         "pt_render_samples": (i32, [vp, u32, u32, i32, vp]),
+        "pt_render_flush": (i32, [vp]),
         "pt_readback_current": (i32, [vp, vp]),
         "pt_readback_accumulation": (i32, [vp, vp]),
         "pt_readback_raystack": (i32, [vp, vp, vp]),
@@ -390,6 +392,10 @@ class PathTracer:
         rc = np.zeros(2 * max(self.slots, 1), dtype=np.uint64) if want_ray_counts else None
         self._chk(self._L.pt_render_samples(self._h, first_frame_index, num_frames, int(speculative_depth0), _p(rc)))
         return rc
+
+    def render_flush(self):
+        """Finishes the frames a kept frame train still holds (OPT_TRAIN_KEEP = 1); nothing to do otherwise."""
+        self._chk(self._L.pt_render_flush(self._h))
 
     # read-back --------------------------------------------------------------------------------
     def readback_accumulation(self):

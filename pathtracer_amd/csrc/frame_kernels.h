@@ -38,7 +38,7 @@ __host__ __device__ constexpr uint32_t ctr_words(uint32_t slots) { return CTR_SH
 /* Counters of the frame train (several frames, each at its own depth, stepped together): the first three are the words the
    shade pass already uses under the names above. */
 enum {
-    TC_NJOBS = 0,         /* entries of the step's job list: the survivors of the last step's shade pass + the new frame's pixels */
+    TC_NJOBS = 0,         /* entries of the step's job list: the survivors of the last step's shade pass + the pixels of a frame that enters */
     TC_FETCH = 1,
     TC_OUT = 2,           /* entries the shade pass has appended to the next step's list */
     TC_BASE = 3,          /* where the launch pass puts the new frame's jobs: behind the survivors */
@@ -76,7 +76,6 @@ struct FrameArgs {
     uint32_t slotBase;               /* launch: index of the frame's first slot in the ring of ray stacks (jobs carry ring-wide slot indices;
                                         `stack` is the ring's base for the shade pass, the frame's own stack for launch and resolve) */
     uint32_t row0, row1;             /* launch, resolve: the rows of the image this part of the train renders ([0, H) elsewhere) */
-    uint32_t injectNext;             /* step end: jobs the next step's launch pass will add */
     uint32_t shadowQueue;            /* step end: the queue this step's traversal launch emptied */
 };
 
@@ -95,6 +94,9 @@ __global__ __launch_bounds__(256) void k_launch_t(FrameArgs f)
         f.ctr[CTR_NJOBS] = f.W * f.H;
         for (uint32_t k = 1; k < ctr_words(f.slots); k++) f.ctr[k] = 0;            /* the frame starts from clean counters */
     }
+    /* the train's step list grows by this part's pixels, behind the survivors of the last step's shade pass (nothing reads
+       the length before this launch has ended; the other threads read TC_BASE only) */
+    if (TRAIN && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) f.ctr[TC_NJOBS] = f.ctr[TC_BASE] + (f.row1 - f.row0) * f.W;
     if ((float)lx >= f.c.viewportSize[0] || (float)ly >= f.c.viewportSize[1]) return;
     if (TRAIN && gy >= f.row1) return;
     uint32_t jitter = (uint32_t)f.blueNoise[(lx & 0xFF) + ((ly & 0xFF) << 8)] * 256u + (uint32_t)f.blueNoise[f.c.frameIndex & 0xFFFF];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void k_launch_t(FrameArgs f)
     sp[0] = make_float4(d.x * inv, d.y * inv, d.z * inv, __uint_as_float(rs));
     sp[1] = make_float4(cam[0], cam[1], cam[2], __uint_as_float(0u));
     s->prob = 0;
-    /* (the step's counters were set when the last step ended; a part's jobs are its own rows') */
+    /* (TC_BASE was set when the last step ended; a part's jobs are its own rows') */
     if (TRAIN) f.jobs[f.ctr[TC_BASE] + (jobIndex - f.row0 * (uint32_t)f.c.viewportSize[0])] = f.slotBase + stackIndex;
     else f.jobs[jobIndex] = stackIndex;
 }
@@ -351,13 +353,14 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_train(FrameArgs f)
     }
 }
 
-/* Ends a step of the frame train; one thread.  The list the shade pass appended to becomes the next step's list, with room
- * behind it for the frame that step's launch pass adds; the shadow queue this step's traversal launch emptied is free again. */
+/* Ends a step of the frame train; one thread.  The list the shade pass appended to becomes the next step's list (a frame
+ * that enters in that step puts its jobs behind it, k_launch_t); the shadow queue this step's traversal launch emptied is
+ * free again. */
 __global__ void k_train_step_end(FrameArgs f)
 {
     const uint32_t survivors = f.ctr[TC_OUT];
     f.ctr[TC_BASE] = survivors;
-    f.ctr[TC_NJOBS] = survivors + f.injectNext;
+    f.ctr[TC_NJOBS] = survivors;
     f.ctr[TC_OUT] = 0; f.ctr[TC_FETCH] = 0;
     f.ctr[TC_NSHADOW + f.shadowQueue] = 0;
     f.ctr[TC_FLAG] = 0; f.ctr[TC_FLAG + 1] = 0;

@@ -12,6 +12,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -151,6 +152,13 @@ struct FrameTrain {
     TrainPart part[PT_MAX_TRAIN_PARTS];
     uint32_t head = 0;                /* ring position of the most recent frame */
     hipEvent_t evFork = nullptr;
+    /* the train between steps */
+    bool live = false;                /* the parts' counters and lists are those of a train under way (frames may be in flight) */
+    bool forked = false;              /* the parts' streams hold work the context's stream has not waited for */
+    bool stagger = false;             /* the next step starts the parts one launch apart */
+    int cur = 0, q = 0;               /* which job list the next step reads, which shadow queue it traces */
+    uint64_t stepNo = 0;
+    std::deque<std::pair<uint32_t, uint64_t>> flight;     /* ring position and entering step of every frame not yet resolved, oldest first */
 };
 
 struct PtContext {
@@ -188,7 +196,7 @@ struct PtContext {
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 2, optTrainParts = 2, optTrainMaxMB = 0;
+    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 1, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 2, optTrainParts = 2, optTrainMaxMB = 0, optTrainKeep = 0;
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
@@ -202,6 +210,10 @@ struct PtContext {
         hipError_t e_ = (call);                                                                              \
         if (e_ != hipSuccess) return ctx->fail(-10, std::string(#call) + ": " + hipGetErrorString(e_));      \
     } while (0)
+
+static int settle(PtContext* ctx);         /* finishes the frames a kept train still holds */
+static int train_flush(PtContext* ctx);
+static int train_join(PtContext* ctx);
 
 namespace {
 
@@ -229,6 +241,7 @@ void free_train_buffers(FrameTrain& t)
         p.cap = 0;
     }
     t.ready = false; t.F = 0; t.parts = 0; t.head = 0;
+    t.live = t.forked = t.stagger = false; t.flight.clear();
 }
 void free_train(PtContext* c)        /* streams and events stay */
 {
@@ -597,6 +610,7 @@ PT_API int pt_synchronize(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = train_join(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -605,6 +619,7 @@ PT_API void* pt_stream(PtContext* ctx) { return ctx ? (void*)ctx->stream : nullp
 PT_API int pt_set_option(PtContext* ctx, int option, int value)
 {
     if (!ctx) return -1;
+    if (int rc = settle(ctx)) return rc;
     switch (option) {
         case PT_OPT_TRAVERSAL: if (value < 0 || value > 3) return ctx->fail(-1, "PT_OPT_TRAVERSAL must be 0, 1, 2 or 3"); ctx->optTraversal = value; return 0;
         case PT_OPT_STALE_SLOTS: ctx->optStale = value != 0; return 0;
@@ -618,6 +633,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_SHADOW_STREAM: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SHADOW_STREAM must be 0, 1 or 2"); ctx->optShadowStream = value; return 0;
         case PT_OPT_MERGE_PASSES: ctx->optMergePasses = value != 0; return 0;
         case PT_OPT_FRAME_TRAIN: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_FRAME_TRAIN must be 0, 1 or 2"); ctx->optFrameTrain = value; return 0;
+        case PT_OPT_TRAIN_KEEP: ctx->optTrainKeep = value != 0; return 0;
         case PT_OPT_TRAIN_MAX_MB: if (value < 0) return ctx->fail(-1, "PT_OPT_TRAIN_MAX_MB must not be negative"); ctx->optTrainMaxMB = value; return 0;
         case PT_OPT_TRAIN_PARTS: if (value < 1 || value > PT_MAX_TRAIN_PARTS) return ctx->fail(-1, "PT_OPT_TRAIN_PARTS must be 1..4"); ctx->optTrainParts = value; return 0;
         case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
@@ -641,6 +657,7 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_MERGE_PASSES: *value = ctx->optMergePasses; return 0;
         case PT_OPT_FRAME_TRAIN: *value = ctx->optFrameTrain; return 0;
         case PT_OPT_TRAIN_MAX_MB: *value = ctx->optTrainMaxMB; return 0;
+        case PT_OPT_TRAIN_KEEP: *value = ctx->optTrainKeep; return 0;
         case PT_OPT_TRAIN_PARTS: *value = ctx->optTrainParts; return 0;
         case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
         case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;
@@ -654,6 +671,7 @@ PT_API int pt_scene_upload(PtContext* ctx, const float* positions, uint32_t V, c
 try {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (!positions || !indices || !nodes || V == 0 || T == 0) return ctx->fail(-1, "pt_scene_upload: null or empty geometry");
     if (N != 2 * T - 1) return ctx->fail(-1, "pt_scene_upload: node count must be 2*T-1");
     for (size_t i = 0; i < 3 * (size_t)T; i++) if (indices[i] >= V) return ctx->fail(-1, "pt_scene_upload: vertex index out of range");
@@ -773,6 +791,7 @@ PT_API int pt_resize(PtContext* ctx, uint32_t W, uint32_t H, uint32_t max_slots)
     if (int rc = enter(ctx)) return rc;
     if (W == 0 || H == 0 || max_slots == 0) return ctx->fail(-1, "pt_resize: zero dimension");
     if ((uint64_t)W * H * max_slots >= 0xFFFFFFFFull) return ctx->fail(-1, "pt_resize: W*H*slots must fit a 32-bit slot index");
+    if (int rc = settle(ctx)) return rc;
     if (int rc = sync_all(ctx)) return rc;
     free_frame(ctx);
     size_t px = (size_t)W * H;
@@ -796,6 +815,11 @@ PT_API int pt_set_constants(PtContext* ctx, const PtShaderConstants* c)
     if (ctx->slots && (c->numRays == 0 || c->numRays > ctx->slots)) return ctx->fail(-1, "pt_set_constants: numRays exceeds the slots allocated by pt_resize");
     if (ctx->N && c->numBVHNodes != ctx->N) return ctx->fail(-1, "pt_set_constants: numBVHNodes differs from the uploaded scene");
     if (c->viewportBase[0] != 0.0f || c->viewportBase[1] != 0.0f) return ctx->fail(-1, "pt_set_constants: viewportBase must be 0");
+    if (ctx->train.live) {      /* frames in a kept train are finished under the constants they entered with; a new frameIndex alone changes nothing for them */
+        PtShaderConstants was = ctx->consts, now = *c;
+        was.frameIndex = now.frameIndex = 0;
+        if (memcmp(&was, &now, sizeof was)) if (int rc = settle(ctx)) return rc;
+    }
     ctx->consts = *c; ctx->haveConsts = true;
     return 0;
 }
@@ -805,6 +829,7 @@ PT_API int pt_clear_accumulation(PtContext* ctx)
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
+    if (int rc = settle(ctx)) return rc;
     HIPCHK(hipMemsetAsync(ctx->dAccum, 0, (size_t)ctx->W * ctx->H * 16, ctx->stream));
     ctx->accumEmpty = true;
     return 0;
@@ -834,6 +859,7 @@ PT_API int pt_launch(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     return launch_on(ctx, ctx->pipe[0]);
 }
@@ -934,6 +960,7 @@ PT_API int pt_trace(PtContext* ctx, uint32_t depth, int speculative)
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     if (!ctx->dAux || !ctx->dLights) return ctx->fail(-2, "pt_trace: scene was uploaded without vertex attributes or lights");
     if (depth >= ctx->slots) return ctx->fail(-1, "pt_trace: depth exceeds the allocated slots");
@@ -945,6 +972,7 @@ PT_API int pt_compact(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     FramePipe& p = ctx->pipe[0];
     HIPCHK(hipMemsetAsync(p.dCtr + CTR_COMPACT_OUT, 0, 4, p.stream));
@@ -977,6 +1005,7 @@ PT_API int pt_resolve_accumulate(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (int rc = check_frame(ctx)) return rc;
     return resolve_on(ctx, ctx->pipe[0]);
 }
@@ -1010,6 +1039,7 @@ static int ensure_train(PtContext* ctx, uint32_t F, int parts)
     const size_t px = (size_t)ctx->W * ctx->H, stride = px * ctx->slots;
     if ((uint32_t)parts * 8u > ctx->H) parts = 1;
     if (t.ready && t.F >= F && t.parts == parts) return 0;
+    if (int rc = train_flush(ctx)) return rc;              /* frames a kept train holds are finished in the ring as it is */
     if (t.ready && F < t.F) F = t.F;                       /* a change of parts keeps the ring's size */
     for (TrainPart& p : t.part) if (p.stream) HIPCHK(hipStreamSynchronize(p.stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1077,99 +1107,159 @@ static int ensure_train(PtContext* ctx, uint32_t F, int parts)
     return 0;
 }
 
-/* num_frames frames through the frame train. */
-static int train_render(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, uint64_t* ray_counts)
+/* The parts' streams take over from the context's stream: whatever is queued there comes first. */
+static int train_fork(PtContext* ctx)
+{
+    FrameTrain& t = ctx->train;
+    if (t.forked) return 0;
+    HIPCHK(hipEventRecord(t.evFork, ctx->stream));
+    for (int k = 1; k < t.parts; k++) HIPCHK(hipStreamWaitEvent(t.part[k].stream, t.evFork, 0));
+    t.forked = t.stagger = true;
+    return 0;
+}
+
+/* The context's stream waits for everything the parts have queued: what is queued on it next sees every step so far finished. */
+static int train_join(PtContext* ctx)
+{
+    FrameTrain& t = ctx->train;
+    if (!t.forked) return 0;
+    for (int k = 1; k < t.parts; k++) {
+        HIPCHK(hipEventRecord(t.part[k].evDone, t.part[k].stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, t.part[k].evDone, 0));
+    }
+    t.forked = false;
+    return 0;
+}
+
+/* Before the first step of a train that holds no frame: clean counters, lists at their start. */
+static int train_begin(PtContext* ctx)
+{
+    FrameTrain& t = ctx->train;
+    if (int rc = ensure_overflow(ctx)) return rc;
+    if (ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest)      /* the list of jobs for the second walk: allocated before anything is queued */
+        for (int k = 0; k < t.parts; k++) if (!t.part[k].dFlag) HIPCHK(hipMalloc((void**)&t.part[k].dFlag, t.part[k].cap * 4));
+    if (t.live) return train_fork(ctx);
+    if (!ctx->rngInTrain) {      /* the most recent frame's RNG states are in a pipe's stack: the first launch pass reads them there */
+        FramePipe& src = ctx->pipe[ctx->rngPipe];
+        if (src.stream && src.stream != ctx->stream && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(ctx->stream, src.evShade0, 0));
+    }
+    if (int rc = train_fork(ctx)) return rc;
+    for (int k = 0; k < t.parts; k++) HIPCHK(hipMemsetAsync(t.part[k].dCtr, 0, (size_t)TC_WORDS * 4, t.part[k].stream));
+    t.cur = t.q = 0; t.stepNo = 0; t.flight.clear();
+    t.live = true;
+    return 0;
+}
+
+/* One step of the train: a frame enters (or none does, when the train is being emptied), every frame in flight goes one
+ * bounce further, the frame that entered numRays steps ago leaves. */
+static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
 {
     FrameTrain& t = ctx->train;
     const uint32_t nr = ctx->consts.numRays;
     const size_t stride = (size_t)ctx->W * ctx->H * ctx->slots;
-    if (int rc = ensure_overflow(ctx)) return rc;
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (ray_counts) HIPCHK(hipMemsetAsync(t.dRayCounts, 0, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8, ctx->stream));
-    /* where the most recent frame's RNG states are, if not in the ring already: the first launch pass reads them there */
-    const PtRayStackSlot* rngStack = ctx->rngInTrain ? t.dRing + (size_t)t.head * stride : ctx->pipe[ctx->rngPipe].dStack;
-    if (!ctx->rngInTrain) {
-        FramePipe& src = ctx->pipe[ctx->rngPipe];
-        if (src.stream && src.stream != ctx->stream && src.shade0Pending && !ctx->optReseed) HIPCHK(hipStreamWaitEvent(ctx->stream, src.evShade0, 0));
-    }
-    /* the other parts start after whatever is already queued on the context's stream */
-    HIPCHK(hipEventRecord(t.evFork, ctx->stream));
-    for (int k = 1; k < t.parts; k++) HIPCHK(hipStreamWaitEvent(t.part[k].stream, t.evFork, 0));
-    const uint32_t head0 = t.head;
-    auto pos_of = [&](uint32_t i) { return (head0 + 1u + i) % t.F; };
-    const bool seedFirst = ctx->accumEmpty;
     const bool certified = ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest;
-    if (certified)          /* the list of jobs for the second walk: allocated before anything is queued */
-        for (int k = 0; k < t.parts; k++) if (!t.part[k].dFlag) HIPCHK(hipMalloc((void**)&t.part[k].dFlag, t.part[k].cap * 4));
-
+    if (int rc = train_fork(ctx)) return rc;
+    uint32_t pos = 0; const PtRayStackSlot* rngStack = nullptr; bool seed = false;
+    if (enter) {
+        rngStack = ctx->rngInTrain ? t.dRing + (size_t)t.head * stride : ctx->pipe[ctx->rngPipe].dStack;
+        pos = (t.head + 1u) % t.F;
+        seed = ctx->accumEmpty;                                                             /* launch.comp:49-50: this frame's resolve pass is the first since the clear */
+        ctx->consts.frameIndex = frame_index & 0xFFFF;                                      /* PathTracer.cpp:729 */
+        t.flight.push_back({ pos, t.stepNo });
+    }
+    /* the frame that leaves in this step, and how many have an entry in its job list */
+    const bool leaves = !t.flight.empty() && t.flight.front().second + nr == t.stepNo;
+    const uint32_t leavingPos = leaves ? t.flight.front().first : 0u;
+    if (leaves) t.flight.pop_front();
+    const uint32_t shaded = (uint32_t)t.flight.size();
     FrameArgs f; fill_frame_args(ctx, ctx->pipe[0], f);
     f.rayCounts = t.dRayCounts; f.fuseCompact = 1;
+    const int cur = t.cur, q = t.q;
     for (int k = 0; k < t.parts; k++) {
         TrainPart& p = t.part[k];
-        HIPCHK(hipMemsetAsync(p.dCtr, 0, (size_t)TC_WORDS * 4, p.stream));
-        f.ctr = p.dCtr; f.injectNext = (p.row1 - p.row0) * ctx->W; f.shadowQueue = 0;
-        hipLaunchKernelGGL(k_train_step_end, dim3(1), dim3(1), 0, p.stream, f);          /* step 0 starts with the first frame's pixels */
-    }
-    int cur = 0, q = 0;
-    const uint32_t steps = num_frames + nr;
-    for (uint32_t s = 0; s < steps; s++) {
-        for (int k = 0; k < t.parts; k++) {
-            TrainPart& p = t.part[k];
-            const uint32_t ppx = (p.row1 - p.row0) * ctx->W;
-            f.ctr = p.dCtr; f.hitRecs = p.dHitRecs; f.row0 = p.row0; f.row1 = p.row1;
-            if (s < num_frames) {                                                             /* a frame enters */
-                const uint32_t pos = pos_of(s);
-                ctx->consts.frameIndex = (first_frame_index + s) & 0xFFFF;                      /* PathTracer.cpp:729 */
-                f.c = ctx->consts;
-                f.seedFromJitter = (s == 0 && seedFirst) ? 1u : 0u;                             /* launch.comp:49-50: its resolve pass follows within this call */
-                f.stack = t.dRing + (size_t)pos * stride; f.slotBase = (uint32_t)(pos * stride);
-                f.rngStack = s == 0 ? rngStack : t.dRing + (size_t)pos_of(s - 1) * stride;
-                f.jobs = p.dJobs[cur];
-                dim3 grid((ctx->W + 31) / 32, (p.row1 - p.row0 + 7) / 8), block(256);
-                hipLaunchKernelGGL(k_launch_t<true>, grid, block, 0, p.stream, f);
-            }
-            {   /* every frame in flight one bounce further, and the shadow rays of the bounce before */
-                TraceArgs a; fill_trace_args(ctx, a);
-                a.stack = t.dRing; a.hitRecs = p.dHitRecs;
-                a.jobs = p.dJobs[cur]; a.countPtr = p.dCtr + TC_NJOBS; a.fetchCounter = p.dCtr + TC_FETCH;
-                a.shadowRays = p.dShadow[q]; a.countPtr2 = p.dCtr + TC_NSHADOW + q;
-                if (certified) {
-                    if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG)) return rc;
-                } else if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
-            }
-            /* the parts start one after the other, so that their traversal launches do not all thin out at the same time */
-            if (s == 0 && k + 1 < t.parts) {
-                HIPCHK(hipEventRecord(p.evStagger, p.stream));
-                HIPCHK(hipStreamWaitEvent(t.part[k + 1].stream, p.evStagger, 0));
-            }
-            if (s >= nr) {                                                                    /* a frame leaves: its last shadow rays were in that launch */
-                f.stack = t.dRing + (size_t)pos_of(s - nr) * stride;
-                hipLaunchKernelGGL(k_resolve, dim3(((size_t)ppx + 255) / 256), dim3(256), 0, p.stream, f);
-            }
-            const uint32_t firstIn = s + 1 > nr ? s + 1 - nr : 0, lastIn = s < num_frames - 1 ? s : num_frames - 1;     /* frames with a job list entry this step */
-            if (firstIn <= lastIn) {
-                f.stack = t.dRing;
-                f.jobs = p.dJobs[cur]; f.jobsOut = p.dJobs[cur ^ 1];
-                f.shadowRays = p.dShadow[q ^ 1]; f.shadowCtr = p.dCtr + TC_NSHADOW + (q ^ 1);
-                const uint64_t most = (uint64_t)(lastIn - firstIn + 1) * ppx;
-                uint64_t blocks = (most + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
-                const uint64_t wide = (uint64_t)ctx->numCUs * 32;
-                if (blocks > wide) blocks = wide;
-                hipLaunchKernelGGL(k_shade_train, dim3((uint32_t)blocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f);
-            }
-            f.injectNext = s + 1 < num_frames ? ppx : 0u; f.shadowQueue = (uint32_t)q;
-            hipLaunchKernelGGL(k_train_step_end, dim3(1), dim3(1), 0, p.stream, f);
-            HIPCHK(hipGetLastError());
+        const uint32_t ppx = (p.row1 - p.row0) * ctx->W;
+        f.ctr = p.dCtr; f.hitRecs = p.dHitRecs; f.row0 = p.row0; f.row1 = p.row1;
+        if (enter) {
+            f.c = ctx->consts;
+            f.seedFromJitter = seed ? 1u : 0u;
+            f.stack = t.dRing + (size_t)pos * stride; f.slotBase = (uint32_t)(pos * stride);
+            f.rngStack = rngStack;
+            f.jobs = p.dJobs[cur];
+            dim3 grid((ctx->W + 31) / 32, (p.row1 - p.row0 + 7) / 8), block(256);
+            hipLaunchKernelGGL(k_launch_t<true>, grid, block, 0, p.stream, f);
         }
-        cur ^= 1; q ^= 1;
+        {   /* every frame in flight one bounce further, and the shadow rays of the bounce before */
+            TraceArgs a; fill_trace_args(ctx, a);
+            a.stack = t.dRing; a.hitRecs = p.dHitRecs;
+            a.jobs = p.dJobs[cur]; a.countPtr = p.dCtr + TC_NJOBS; a.fetchCounter = p.dCtr + TC_FETCH;
+            a.shadowRays = p.dShadow[q]; a.countPtr2 = p.dCtr + TC_NSHADOW + q;
+            if (certified) {
+                if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG)) return rc;
+            } else if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
+        }
+        /* parts that start from rest start one after the other, so that their traversal launches do not all thin out at the same time */
+        if (t.stagger && k + 1 < t.parts) {
+            HIPCHK(hipEventRecord(p.evStagger, p.stream));
+            HIPCHK(hipStreamWaitEvent(t.part[k + 1].stream, p.evStagger, 0));
+        }
+        if (leaves) {                                                                     /* its last shadow rays were in that launch */
+            f.stack = t.dRing + (size_t)leavingPos * stride;
+            hipLaunchKernelGGL(k_resolve, dim3(((size_t)ppx + 255) / 256), dim3(256), 0, p.stream, f);
+        }
+        if (shaded) {
+            f.stack = t.dRing;
+            f.jobs = p.dJobs[cur]; f.jobsOut = p.dJobs[cur ^ 1];
+            f.shadowRays = p.dShadow[q ^ 1]; f.shadowCtr = p.dCtr + TC_NSHADOW + (q ^ 1);
+            const uint64_t most = (uint64_t)shaded * ppx;
+            uint64_t blocks = (most + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
+            const uint64_t wide = (uint64_t)ctx->numCUs * 32;
+            if (blocks > wide) blocks = wide;
+            hipLaunchKernelGGL(k_shade_train, dim3((uint32_t)blocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f);
+        }
+        f.shadowQueue = (uint32_t)q;
+        hipLaunchKernelGGL(k_train_step_end, dim3(1), dim3(1), 0, p.stream, f);
+        HIPCHK(hipGetLastError());
     }
-    for (int k = 1; k < t.parts; k++) {      /* join: later calls on the context's stream see every part finished */
-        HIPCHK(hipEventRecord(t.part[k].evDone, t.part[k].stream));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, t.part[k].evDone, 0));
+    t.stagger = false;
+    t.cur ^= 1; t.q ^= 1; t.stepNo++;
+    if (enter) {
+        t.head = pos;
+        ctx->accumEmpty = false;
+        ctx->rngInTrain = ctx->lastInTrain = true;
     }
-    t.head = pos_of(num_frames - 1);
-    ctx->accumEmpty = false;
-    ctx->rngInTrain = ctx->lastInTrain = true;
+    return 0;
+}
+
+/* Steps without a new frame until every frame in the train has left it; then the context's stream has everything. */
+static int train_flush(PtContext* ctx)
+{
+    FrameTrain& t = ctx->train;
+    if (!t.live) return 0;
+    while (!t.flight.empty()) if (int rc = train_step(ctx, false, 0)) return rc;
+    t.live = false;
+    return train_join(ctx);
+}
+
+/* What every entry point that reads or changes more than the images calls first: with PT_OPT_TRAIN_KEEP a render call
+ * returns with frames still in the train. */
+static int settle(PtContext* ctx)
+{
+    if (!ctx->train.live) return 0;
+    if (int rc = enter(ctx)) return rc;
+    return train_flush(ctx);
+}
+
+/* num_frames frames through the frame train.  keep: the call ends after num_frames steps, with the last numRays frames still
+ * in the train (a later call carries on from there; train_flush finishes them). */
+static int train_render(PtContext* ctx, uint32_t first_frame_index, uint32_t num_frames, uint64_t* ray_counts, bool keep)
+{
+    FrameTrain& t = ctx->train;
+    const uint32_t nr = ctx->consts.numRays;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (ray_counts) HIPCHK(hipMemsetAsync(t.dRayCounts, 0, (size_t)2 * PT_MAX_TRAIN_DEPTH * 8, ctx->stream));
+    if (int rc = train_begin(ctx)) return rc;
+    for (uint32_t i = 0; i < num_frames; i++) if (int rc = train_step(ctx, true, first_frame_index + i)) return rc;
+    if (!keep) { if (int rc = train_flush(ctx)) return rc; }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->evPending = true;
     if (ray_counts) {
@@ -1195,11 +1285,15 @@ try {
        three frames in flight do as well or better: 1 309 against 1 197 spp/s on the bunny, 289 against 305 on 5.8 M triangles) */
     const bool wantTrain = ctx->optFrameTrain == 1 || (ctx->optFrameTrain == 2 && ctx->consts.numRays >= 3);
     if (wantTrain && !ctx->optStale && !speculative_depth0 && ctx->optTraversal != 0 && ctx->consts.numRays <= PT_MAX_TRAIN_DEPTH) {
-        const uint32_t want = num_frames < ctx->consts.numRays + 1 ? num_frames : ctx->consts.numRays + 1;
+        /* ray counts are those of this call's frames: nothing of an earlier call in the train, nothing of this one left in it */
+        const bool keep = ctx->optTrainKeep && !ray_counts;
+        if (!keep) if (int rc = settle(ctx)) return rc;
+        const uint32_t want = !keep && num_frames < ctx->consts.numRays + 1 ? num_frames : ctx->consts.numRays + 1;
         const int rc = ensure_train(ctx, want, ctx->optTrainParts);
         if (rc < 0) return rc;
-        if (rc == 0) return train_render(ctx, first_frame_index, num_frames, ray_counts);
+        if (rc == 0) return train_render(ctx, first_frame_index, num_frames, ray_counts, keep);
     }
+    if (int rc = settle(ctx)) return rc;
     /* the reference's stale-slot behaviour needs every frame on the one ray stack */
     int K = ctx->optStale ? 1 : ctx->optFramesInFlight;
     if ((uint32_t)K > num_frames) K = (int)num_frames;
@@ -1238,11 +1332,19 @@ PT_API int pt_render_sample(PtContext* ctx, uint32_t frame_index, int speculativ
     return pt_render_samples(ctx, frame_index, 1, speculative_depth0, ray_counts);
 }
 
+PT_API int pt_render_flush(PtContext* ctx)
+{
+    if (!ctx) return -1;
+    if (int rc = enter(ctx)) return rc;
+    return settle(ctx);
+}
+
 PT_API int pt_readback_current(PtContext* ctx, uint16_t* rgba16f)
 {
     if (!ctx || !rgba16f) return -1;
     if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
+    if (int rc = train_join(ctx)) return rc;           /* with a kept train: the frames resolved so far */
     HIPCHK(hipMemcpyAsync(rgba16f, ctx->dCurrent, (size_t)ctx->W * ctx->H * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1252,6 +1354,7 @@ PT_API int pt_readback_accumulation(PtContext* ctx, float* rgba32f)
     if (!ctx || !rgba32f) return -1;
     if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
+    if (int rc = train_join(ctx)) return rc;           /* with a kept train: the frames resolved so far */
     HIPCHK(hipMemcpyAsync(rgba32f, ctx->dAccum, (size_t)ctx->W * ctx->H * 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -1260,6 +1363,7 @@ PT_API int pt_readback_raystack(PtContext* ctx, PtRayStackSlot* slots, PtRayJob*
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
     FramePipe& p = ctx->pipe[ctx->lastPipe];           /* the stack and job list of the most recent frame */
@@ -1279,6 +1383,7 @@ PT_API int pt_upload_raystack(PtContext* ctx, const PtRayStackSlot* slots, const
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     size_t px = (size_t)ctx->W * ctx->H;
     FramePipe& p = ctx->pipe[0];                        /* the dispatch-site calls that follow work on pipe 0 */
@@ -1315,6 +1420,7 @@ PT_API int pt_tonemap(PtContext* ctx, float* rgb32f, uint8_t* rgba8)
     if (int rc = enter(ctx)) return rc;
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     if (!rgb32f && !rgba8) return 0;
+    if (int rc = train_join(ctx)) return rc;           /* with a kept train: the frames resolved so far */
     const size_t px = (size_t)ctx->W * ctx->H;
     float* dF = nullptr; uint32_t* dB = nullptr;
     if (rgb32f) HIPCHK(hipMalloc((void**)&dF, px * 12));
@@ -1407,6 +1513,7 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (int rc = check_scene(ctx)) return rc;
     if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays: null buffer");
     /* the id counter is 32 bits wide and every wavefront may overshoot the count by one chunk */
@@ -1420,6 +1527,7 @@ PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t n
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (int rc = check_scene(ctx)) return rc;
     if (!d_rays || !d_hits) return ctx->fail(-1, "pt_trace_rays_noalloc: null buffer");
     if (num_rays > NA_MAX_RAYS) return ctx->fail(-1, "pt_trace_rays_noalloc: at most 2^21 (2 097 152) rays per call; larger batches need pt_trace_rays");
@@ -1575,6 +1683,7 @@ PT_API int pt_allreduce_accumulation(PtContext* ctx)
 {
     if (!ctx) return -1;
     if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
     if (!ctx->comm) return ctx->fail(-2, "pt_allreduce_accumulation: call pt_comm_init first");
     if (!ctx->W) return ctx->fail(-2, "no frame resources");
     /* one sum over RGBA32F: .w carries the sample count and sums with the radiance */

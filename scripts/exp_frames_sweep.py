@@ -14,6 +14,8 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--layout", type=int, default=0)
 ap.add_argument("--slots", default="8")
 ap.add_argument("--bits", type=int, default=4)
+ap.add_argument("--keep", type=int, default=0, help="PT_OPT_TRAIN_KEEP: the train is kept between calls (flushed inside the timed region at the end)")
+ap.add_argument("--percall", type=int, default=0, help="frames per pt_render_samples call (a synchronize after each); 0 = all in one call")
 lists = ("train", "parts", "merge", "blocks", "refill", "inflight")
 defaults = dict(train="1", parts="2", merge="1", blocks="0", refill="0", inflight="3")
 for name in lists:
@@ -41,12 +43,19 @@ for trav, NR in itertools.product([int(v) for v in args.traversal.split(",")], [
         ctx.set_constants(pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **cam))
         for o, v in ((core.OPT_FRAMES_IN_FLIGHT, inflight), (core.OPT_MERGE_PASSES, merge), (core.OPT_FRAME_TRAIN, train), (core.OPT_TRAIN_PARTS, parts)):
             ctx.set_option(o, v)
+        ctx.set_option(core.OPT_TRAIN_KEEP, args.keep)
         if blocks: ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
         if refill: ctx.set_option(core.OPT_REFILL_MIN, refill)
         ctx.render_samples(1, 12); ctx.synchronize()
         t = time.perf_counter()
-        ctx.render_samples(100, args.frames); ctx.synchronize()
+        if args.percall:
+            for first in range(100, 100 + args.frames, args.percall):
+                ctx.render_samples(first, min(args.percall, 100 + args.frames - first))
+                if not args.keep: ctx.synchronize()
+            ctx.render_flush(); ctx.synchronize()
+        else:
+            ctx.render_samples(100, args.frames); ctx.synchronize()
         dt = time.perf_counter() - t
         print(f"{args.scene} {W}x{H} slots {NR} traversal {trav} train {train} parts {parts} merge {merge} blocks {blocks} refill {refill} in flight {inflight}: "
-              f"{args.frames / dt:.1f} spp/s ({args.frames} frames in {args.frames + NR if train else args.frames} steps)", flush=True)
+              f"{args.frames / dt:.1f} spp/s ({args.frames} frames in {args.frames + NR if train else args.frames} steps{f', {args.percall} per call' if args.percall else ''}{', train kept' if args.keep else ''})", flush=True)
         ctx.close()

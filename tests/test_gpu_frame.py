@@ -24,7 +24,7 @@ def _setup(ctx, model, W, H, NR):
     helpers.upload(ctx, model, lights, bn)
     ctx.resize(W, H, NR)
     for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT), (core.OPT_STALE_SLOTS, 0), (core.OPT_RESEED, 0), (core.OPT_FRAMES_IN_FLIGHT, 2),
-                 (core.OPT_FRAME_TRAIN, 1), (core.OPT_TRAIN_PARTS, 2), (core.OPT_TRAIN_MAX_MB, 0), (core.OPT_MERGE_PASSES, 1), (core.OPT_SHADOW_STREAM, 2)):
+                 (core.OPT_FRAME_TRAIN, 1), (core.OPT_TRAIN_PARTS, 2), (core.OPT_TRAIN_MAX_MB, 0), (core.OPT_TRAIN_KEEP, 0), (core.OPT_MERGE_PASSES, 1), (core.OPT_SHADOW_STREAM, 2)):
         ctx.set_option(o, v)
     return helpers.oracle_scene(model, lights, bn), oracle.Frame(W, H, NR)
 
@@ -484,6 +484,101 @@ def test_frame_train_equals_sequential(gpu_ctx, oracle_lib, monkey, trav, reseed
     gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 2)
 
 
+@pytest.mark.parametrize("trav,parts", [(core.TRAVERSAL_FLAT, 2), (core.TRAVERSAL_CERTIFIED, 3), (core.TRAVERSAL_FLAT, 1)])
+def test_kept_train_equals_sequential(gpu_ctx, oracle_lib, monkey, trav, parts):
+    """PT_OPT_TRAIN_KEEP: render calls return with frames still in the train.  One frame per call, as the reference's
+    render thread asks for them: the accumulation read between calls is the oracle's after the frames that have left the
+    train (it lags numRays frames behind), pt_render_flush and every call that must see finished frames (clear, ray-stack
+    read, changed constants, options, a call that wants ray counts, the dispatch sites) bring every buffer to what
+    frame-by-frame rendering leaves."""
+    W, H, NR = 160, 88, 4
+    osc, fr = _setup(gpu_ctx, monkey, W, H, NR)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
+    gpu_ctx.set_option(core.OPT_TRAIN_PARTS, parts)
+    gpu_ctx.set_option(core.OPT_TRAIN_KEEP, 1)
+    mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS
+    c = _consts(monkey, W, H, NR, 1, {})
+    frame = 1                 # next frame index, the same on both sides
+    snaps = [fr.accumulation.copy()]          # the oracle's accumulation after 0, 1, 2, ... frames since the last clear
+
+    def both(n, per_call=1):
+        nonlocal frame
+        for first in range(frame, frame + n, per_call):
+            k = min(per_call, frame + n - first)
+            c["frameIndex"] = first
+            gpu_ctx.set_constants(c)                  # a new frameIndex alone leaves the train as it is
+            gpu_ctx.render_samples(first, k)
+            for i in range(k):
+                c["frameIndex"] = first + i
+                oracle.render_frame(osc, fr, c, mode=mode)
+                snaps.append(fr.accumulation.copy())
+        frame += n
+
+    both(2)                                           # fewer calls than the path is deep: nothing has left the train
+    assert (gpu_ctx.readback_accumulation() == 0).all()
+    both(5)
+    acc = gpu_ctx.readback_accumulation()             # 7 frames entered, 3 left
+    assert (acc[..., 3] == 7 - NR).all() and np.array_equal(acc, snaps[7 - NR])
+    gpu_ctx.synchronize()
+    both(3, per_call=2)                               # calls of two frames and of one
+    acc = gpu_ctx.readback_accumulation()
+    assert np.array_equal(acc, snaps[10 - NR])
+    gpu_ctx.render_flush()
+    _compare(gpu_ctx, fr, live_slots_only=True)
+    gpu_ctx.render_flush()                            # nothing left to do
+    both(6)
+    _compare(gpu_ctx, fr, live_slots_only=True)       # the ray-stack read finishes the frames first
+    both(3)
+    gpu_ctx.clear_accumulation(); fr.clear_accumulation(); snaps[:] = [fr.accumulation.copy()]
+    both(NR + 2)
+    acc = gpu_ctx.readback_accumulation()
+    assert np.array_equal(acc, snaps[2])
+    # a call that wants ray counts counts its own frames only, and returns with them finished
+    before = fr.ray_counts().copy()
+    rc = gpu_ctx.render_samples(frame, 3, want_ray_counts=True)
+    for i in range(3):
+        c["frameIndex"] = frame + i
+        oracle.render_frame(osc, fr, c, mode=mode)
+    frame += 3
+    after = fr.ray_counts()
+    assert int(rc[0::2][:NR].sum()) == int(after[0] - before[0]) and int(rc[1::2][:NR].sum()) == int(after[1] - before[1])
+    _compare(gpu_ctx, fr, live_slots_only=True)
+    # constants that differ in more than the frame index: the frames in flight are finished under the old ones
+    both(3)
+    c2 = _consts(monkey, W, H, NR, frame, dict(orbit_angle=0.4))
+    gpu_ctx.set_constants(c2)
+    gpu_ctx.render_samples(frame, 2)
+    for i in range(2):
+        c2["frameIndex"] = frame + i
+        oracle.render_frame(osc, fr, c2, mode=mode)
+    frame += 2
+    # the dispatch sites take over from a train with frames in it
+    c2["frameIndex"] = frame
+    gpu_ctx.set_constants(c2)
+    gpu_ctx.launch()
+    for d in range(NR):
+        gpu_ctx.trace(d)
+    gpu_ctx.resolve_accumulate()
+    oracle.render_frame(osc, fr, c2, mode=mode)
+    frame += 1
+    _compare(gpu_ctx, fr, live_slots_only=True)
+    # an option change with frames in flight, then a resize
+    gpu_ctx.render_samples(frame, 3)
+    for i in range(3):
+        c2["frameIndex"] = frame + i
+        oracle.render_frame(osc, fr, c2, mode=mode)
+    frame += 3
+    gpu_ctx.set_option(core.OPT_TRAIN_KEEP, 0)
+    assert np.array_equal(gpu_ctx.readback_accumulation(), fr.accumulation)
+    gpu_ctx.set_option(core.OPT_TRAIN_KEEP, 1)
+    gpu_ctx.render_samples(frame, 2)
+    gpu_ctx.resize(W, H, NR)                          # frames in flight are finished into buffers that are then replaced
+    assert (gpu_ctx.readback_accumulation() == 0).all()
+    gpu_ctx.set_option(core.OPT_TRAIN_KEEP, 0)
+    gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 2)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+
+
 def test_cornell_box_512_four_bounces(gpu_ctx, oracle_lib):
     """The plumbing configuration: Cornell box (stand-in geometry, 34 triangles) at 512 x 512 with 4 bounces from the
     reference's default camera; every buffer equals the oracle's after two frames."""
@@ -721,7 +816,8 @@ def test_cpp_host_renders_what_the_python_host_renders(gpu_ctx, bunny, tmp_path)
     """examples/pt_host.cpp - a C++ program that links libptcore.so and nothing else, and follows the reference's render
     thread through the C ABI (load, BuildBVH, upload, per frame launch / trace / raysort / composite) - leaves the
     accumulation this Python host leaves for the same frames, byte for byte (compared by hash), through the dispatch sites
-    and through one pt_render_samples call; its frame dump and picture are there."""
+    through one pt_render_samples call and through one call per frame with the frame train kept between the calls; its frame
+    dump and picture are there."""
     import os, re, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "pt_host")
@@ -731,7 +827,7 @@ def test_cpp_host_renders_what_the_python_host_renders(gpu_ctx, bunny, tmp_path)
     model = os.path.join(root, "tests", "golden", "models", "CBbunny.ply")
     noise = os.path.join(root, "pathtracer_amd", "data", "blue_noise_u16le.bin")
     hashes = {}
-    for mode in ("sites", "batch"):
+    for mode in ("sites", "batch", "kept"):
         out = tmp_path / mode
         out.mkdir()
         r = subprocess.run([exe, model, noise, str(out), str(W), str(H), str(NR), str(NF), mode], capture_output=True, text=True, timeout=120)
@@ -740,7 +836,7 @@ def test_cpp_host_renders_what_the_python_host_renders(gpu_ctx, bunny, tmp_path)
         assert m and int(m.group(2)) == NF, r.stdout
         hashes[mode] = m.group(1)
         assert (out / f"RayStackBuffer_{NF}.bin.z").exists() and (out / "pt_host.ppm").stat().st_size > W * H * 3
-    assert hashes["sites"] == hashes["batch"]
+    assert hashes["sites"] == hashes["batch"] == hashes["kept"]
     _setup(gpu_ctx, bunny, W, H, NR)
     gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)      # the library's default, which the C++ host runs with
     for frame in range(1, NF + 1):
