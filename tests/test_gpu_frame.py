@@ -856,7 +856,8 @@ def test_frame_train_random_configurations(bunny, monkey):
     """Randomised differential test (fixed seed; scripts/exp_fuzz_frames.py is the long-running twin): random image sizes,
     path depths, slot counts, traversals, record layouts, reseeding, numbers of bands and sequences of call lengths with a clear
     in between - the frame train leaves the accumulation, the current image, the per-depth ray counts and the live part of the
-    ray stack that the per-frame pipeline leaves for the same calls."""
+    ray stack that the per-frame pipeline leaves for the same calls, and so does the train kept between calls
+    (PT_OPT_TRAIN_KEEP) with every call cut into random pieces and reads that do not empty it in between."""
     rng = np.random.default_rng(20261111)
     for case in range(24):
         model = (bunny, monkey)[int(rng.integers(2))]
@@ -867,19 +868,29 @@ def test_frame_train_random_configurations(bunny, monkey):
         in_flight = int(rng.integers(1, 5))
         desc = f"case {case}: {W}x{H} slots {slots} numRays {NR} traversal {trav} layout {layout} reseed {reseed} bands {parts} calls {calls}"
         out = {}
-        for train in (1, 0):
+        rng2 = np.random.default_rng(case)
+        for train in (1, 0, 2):               # 2: the train kept between calls, every call cut into random pieces
             ctx = pt.PathTracer(0)
             try:
                 ctx.set_option(core.OPT_RECORD_LAYOUT, layout)
                 helpers.upload(ctx, model, pt.default_lights(), pt.load_blue_noise())
                 ctx.resize(W, H, slots)
-                for o, v in ((core.OPT_TRAVERSAL, trav), (core.OPT_RESEED, reseed), (core.OPT_FRAME_TRAIN, train), (core.OPT_TRAIN_PARTS, parts),
-                             (core.OPT_FRAMES_IN_FLIGHT, in_flight)):
+                for o, v in ((core.OPT_TRAVERSAL, trav), (core.OPT_RESEED, reseed), (core.OPT_FRAME_TRAIN, min(train, 1)), (core.OPT_TRAIN_PARTS, parts),
+                             (core.OPT_FRAMES_IN_FLIGHT, in_flight), (core.OPT_TRAIN_KEEP, int(train == 2))):
                     ctx.set_option(o, v)
                 ctx.set_constants(_consts(model, W, H, NR, 1, BUNNY_CAM))
                 frame, rcs = 1, []
                 for k, n in enumerate(calls):
-                    rcs.append(ctx.render_samples(frame, n, want_ray_counts=True)[:2 * NR].copy()); frame += n
+                    if train == 2:
+                        left = n
+                        while left:
+                            m = int(rng2.integers(1, left + 1))
+                            ctx.set_constants(_consts(model, W, H, NR, frame, BUNNY_CAM))      # a new frameIndex alone leaves the train alone
+                            ctx.render_samples(frame, m); frame += m; left -= m
+                            (ctx.readback_accumulation, ctx.synchronize, ctx.readback_current, lambda: None)[int(rng2.integers(4))]()
+                        rcs.append(out[1][2][2 * NR * k:2 * NR * (k + 1)])        # (asking for ray counts would empty the train)
+                    else:
+                        rcs.append(ctx.render_samples(frame, n, want_ray_counts=True)[:2 * NR].copy()); frame += n
                     if k == 1:
                         ctx.clear_accumulation()           # the next call's first frame reseeds from its jitter
                 stack, _ = ctx.readback_raystack()
@@ -887,9 +898,10 @@ def test_frame_train_random_configurations(bunny, monkey):
                               stack[:W * H * NR].reshape(W * H, NR))          # a pixel's slots lie numRays apart
             finally:
                 ctx.close()
-        a, b = out[1], out[0]
-        for k, what in enumerate(("accumulation", "current image", "ray counts")):
-            assert np.array_equal(np.asarray(a[k]).view(np.uint8), np.asarray(b[k]).view(np.uint8)), f"{desc}: {what} differs"
+        b = out[0]
         prob = b[3]["prob"].view(np.float16).astype(np.float32)
         live = np.cumprod(np.concatenate([np.ones((prob.shape[0], 1), bool), prob[:, :-1] > 0], axis=1), axis=1).astype(bool) & (prob > 0)
-        assert np.array_equal(a[3][live].view(np.uint8), b[3][live].view(np.uint8)), f"{desc}: ray stack differs in a live slot"
+        for a, how in ((out[1], "train"), (out[2], "kept train")):
+            for k, what in enumerate(("accumulation", "current image", "ray counts")):
+                assert np.array_equal(np.asarray(a[k]).view(np.uint8), np.asarray(b[k]).view(np.uint8)), f"{desc}: {what} differs ({how})"
+            assert np.array_equal(a[3][live].view(np.uint8), b[3][live].view(np.uint8)), f"{desc}: ray stack differs in a live slot ({how})"
