@@ -389,8 +389,10 @@ int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, boo
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
     a.overflowEntries = ctx->overflowEntries;
-    /* two passes' rays in one pool: one more workgroup per CU than a pass alone gets (measured: 3, 4, 5 -> 158, 160, 161 spp/s) */
-    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : (train ? 6 : 4))), block(PT_BLOCK);     /* the train's launches are batch-sized */
+    /* two passes' rays in one pool: one more workgroup per CU than a pass alone gets (measured: 3, 4, 5 -> 158, 160, 161 spp/s).
+       The train's launches are batch-sized, but six workgroups per CU leave the other band's shade, launch and resolve passes
+       no wave slots beside them: 3, 4, 5, 6 -> 183, 189, 194, 189 spp/s (atrium: 5, 6 -> 209, 197) */
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : (train ? 5 : 4))), block(PT_BLOCK);
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
     const bool ordered = ctx->optTraversal == 2;      /* 3 comes here where the certified walk is not to be had: reference order */
     if (ctx->dTreelets) {
