@@ -286,7 +286,8 @@ enum {
                                     number of hardware queues; needs traversal 1 or 2, otherwise the passes stay apart.
                                     Results do not depend on it */
     PT_OPT_FRAME_TRAIN    = 14,  /* pt_render_sample[s]: 0 = never, 1 = wherever it can serve, 2 (default) = where it can serve and
-                                    numRays >= 3 (with one bounce three frames in flight do as well).  The frame train: the
+                                    numRays >= 3 or the scene's traversal records exceed 8 MiB (a small scene with one bounce
+                                    or none runs better three frames in flight).  The frame train: the
                                     frames of a call advance together, one bounce per step:
                                     a step is one launch pass (the frame that enters), one traversal launch over the
                                     closest-hit rays of every frame in flight and the shadow rays of the step before, one

@@ -44,7 +44,7 @@ OPT_MERGE_PASSES = 13
 OPT_TRAIN_MAX_MB = 16            # most device memory (MiB) the frame train may take; 0 = no limit
 OPT_TRAIN_KEEP = 17              # 1: the frame train is kept between render calls (frames stay in flight; render_flush finishes them)
 OPT_TRAIN_PARTS = 15             # 1..4: bands of rows the frame train renders side by side
-OPT_FRAME_TRAIN = 14             # pt_render_samples steps its frames together, one traversal launch per step: 0 never, 1 always, 2 = for numRays >= 3 (default)
+OPT_FRAME_TRAIN = 14             # pt_render_samples steps its frames together, one traversal launch per step: 0 never, 1 always, 2 = for numRays >= 3 or scenes of more than 8 MiB of records (default)
 OPT_SECOND_WALK = 11            # certified walk's second pass: 0 = a ray per lane, 1 = a ray per wavefront (default)
 OPT_RECORD_LAYOUT = 8           # 0 = 64 B records, 1 = 48 B records, 2 = 128 B treelet records beside the 64 B ones
 LAYOUT_RECORDS64, LAYOUT_RECORDS48, LAYOUT_TREELETS = 0, 1, 2

@@ -276,7 +276,17 @@ void free_frame(PtContext* c)
  * (several of them share the CUs at any time, and their rays are coherent).  PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN
  * override all three. */
 enum { SHAPE_BATCH = 0, SHAPE_ORDERED_BATCH = 1, SHAPE_FRAME = 2 };
-int blocks_per_cu(PtContext* c, int shape) { static const int d[3] = { 5, 6, 3 }; return c->userBlocks ? c->optBlocksPerCU : d[shape]; }
+/* A scene whose traversal records an XCD's L2 holds twice over (CBbunny: 3.6 MB): its walks are short, a frame's time goes to
+ * the passes between them, and narrow traversal launches that leave those passes wave slots do better (1080p, CBbunny,
+ * primary + 1 bounce, three frames in flight: 2 / 3 / 5 workgroups per CU -> 1 416 / 1 349 / 1 124 spp/s; on 33 MB and 742 MB of
+ * records three is as good or better). */
+bool small_scene(const PtContext* c) { return (uint64_t)c->N * 64u <= (8u << 20); }
+int blocks_per_cu(PtContext* c, int shape)
+{
+    static const int d[3] = { 5, 6, 3 };
+    if (c->userBlocks) return c->optBlocksPerCU;
+    return shape == SHAPE_FRAME && small_scene(c) ? 2 : d[shape];
+}
 int refill_min(PtContext* c, int shape) { static const int d[3] = { 36, 24, 12 }; return c->userRefill ? c->optRefillMin : d[shape]; }
 int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 6 || c->userBlocks ? c->optBlocksPerCU : 6); }   /* sizes the spill areas */
 
@@ -392,7 +402,8 @@ int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, boo
     /* two passes' rays in one pool: one more workgroup per CU than a pass alone gets (measured: 3, 4, 5 -> 158, 160, 161 spp/s).
        The train's launches are batch-sized, but six workgroups per CU leave the other band's shade, launch and resolve passes
        no wave slots beside them: 3, 4, 5, 6 -> 183, 189, 194, 189 spp/s (atrium: 5, 6 -> 209, 197) */
-    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : (train ? 5 : 4))), block(PT_BLOCK);
+    const int wide = small_scene(ctx) ? (train ? 4 : 2) : (train ? 5 : 4);      /* small scene, train: 3, 4, 5 -> 978, 1 025, 999 spp/s at 8 slots */
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : wide)), block(PT_BLOCK);
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
     const bool ordered = ctx->optTraversal == 2;      /* 3 comes here where the certified walk is not to be had: reference order */
     if (ctx->dTreelets) {
@@ -455,7 +466,7 @@ int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area
     a.overflowEntries = ctx->overflowEntries;
     a.flagList = flag; a.flagCount = ctr;
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
-    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : 6)), block(PT_BLOCK);
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : small_scene(ctx) ? 3 : 6)), block(PT_BLOCK);      /* small scene: 2 ... 6 -> 402, 415, 402, 383, 382 spp/s */
     hipLaunchKernelGGL((k_trace_cert<MODE_MIXED, false>), grid, block, 0, stream, a);
     HIPCHK(hipGetLastError());
     TraceArgs b = a;
@@ -1283,9 +1294,10 @@ try {
     if (num_frames == 0) return 0;
     /* the frame train serves whatever its one traversal launch per step can: near-first and reference-order walks on 64 B
        or 48 B records.  (The stale-slot behaviour needs every frame on the one ray stack; the voting build its own launches.) */
-    /* (2 = auto, the default: the train where paths are deep enough for it to pay.  With one bounce the per-frame pipeline's
-       three frames in flight do as well or better: 1 309 against 1 197 spp/s on the bunny, 289 against 305 on 5.8 M triangles) */
-    const bool wantTrain = ctx->optFrameTrain == 1 || (ctx->optFrameTrain == 2 && ctx->consts.numRays >= 3);
+    /* (2 = auto, the default: the train where it pays.  On a small scene with one bounce or none the per-frame pipeline's three
+       frames in flight do better: 1 416 against 1 308 spp/s on the bunny at numRays = 2, 1 962 against 1 686 at 1; on 262 k
+       triangles the train is ahead at any depth: 372 against 352 and 644 against 561, on 5.8 M 319 against 294 and 507 against 432) */
+    const bool wantTrain = ctx->optFrameTrain == 1 || (ctx->optFrameTrain == 2 && (ctx->consts.numRays >= 3 || !small_scene(ctx)));
     if (wantTrain && !ctx->optStale && !speculative_depth0 && ctx->optTraversal != 0 && ctx->consts.numRays <= PT_MAX_TRAIN_DEPTH) {
         /* ray counts are those of this call's frames: nothing of an earlier call in the train, nothing of this one left in it */
         const bool keep = ctx->optTrainKeep && !ray_counts;
