@@ -30,6 +30,26 @@ for trav in (2, 3, 1):
         out[(train, parts)] = (ctx.readback_accumulation(), ctx.readback_current(), rc)
         print(f"traversal {trav} train {train} bands {parts}: {NF} frames in {dt:.2f} s", flush=True)
         ctx.close()
+    # the train kept between calls: one frame per call, the accumulation read back (without emptying the train) every 97 frames
+    ctx = pt.PathTracer(0)
+    ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
+    ctx.set_option(core.OPT_TRAVERSAL, trav)
+    ctx.resize(W, H, NR)
+    consts = pt.fill_constants(W, H, NR, ridx.shape[0], nodes.shape[0], **cam)
+    ctx.set_option(core.OPT_FRAME_TRAIN, 1); ctx.set_option(core.OPT_TRAIN_KEEP, 1)
+    t = time.perf_counter()
+    for f in range(1, NF + 1):
+        consts["frameIndex"] = f
+        ctx.set_constants(consts)
+        ctx.render_sample(f)
+        if f % 97 == 0:
+            w = ctx.readback_accumulation()[..., 3]
+            assert (w == f - NR).all(), (f, float(w.min()), float(w.max()))
+    ctx.render_flush(); ctx.synchronize()
+    dt = time.perf_counter() - t
+    out[("kept", 2)] = (ctx.readback_accumulation(), ctx.readback_current(), out[(0, 1)][2])
+    print(f"traversal {trav} train kept, one frame per call: {NF} frames in {dt:.2f} s", flush=True)
+    ctx.close()
     ref = out[(0, 1)]
     for key, got in out.items():
         same = all(np.array_equal(np.asarray(ref[k]).view(np.uint8), np.asarray(got[k]).view(np.uint8)) for k in range(3))
