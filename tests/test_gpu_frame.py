@@ -579,6 +579,42 @@ def test_kept_train_equals_sequential(gpu_ctx, oracle_lib, monkey, trav, parts):
     gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
 
 
+def test_kept_train_scene_swap_two_contexts_and_destroy(oracle_lib, monkey, bunny):
+    """Frames in a kept train when the scene is replaced are finished on the scene they entered with; two contexts on one
+    device keep trains of their own; a context destroyed with frames in flight goes quietly."""
+    W, H, NR = 96, 64, 3
+    mode = oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS
+    a, b = pt.PathTracer(0), pt.PathTracer(0)
+    try:
+        osc_a, fr_a = _setup(a, monkey, W, H, NR)
+        osc_b, fr_b = _setup(b, bunny, W, H, NR)
+        for ctx in (a, b):
+            ctx.set_option(core.OPT_TRAIN_KEEP, 1)
+        ca, cb = _consts(monkey, W, H, NR, 1, {}), _consts(bunny, W, H, NR, 1, BUNNY_CAM)
+        a.set_constants(ca); b.set_constants(cb)
+        for frame in range(1, 6):                       # alternating calls, one frame each
+            a.render_sample(frame); b.render_sample(frame)
+            ca["frameIndex"] = cb["frameIndex"] = frame
+            oracle.render_frame(osc_a, fr_a, ca, mode=mode)
+            oracle.render_frame(osc_b, fr_b, cb, mode=mode)
+        # a gets b's scene with three frames in flight: they finish on the monkey
+        helpers.upload(a, bunny, pt.default_lights(), pt.load_blue_noise())
+        assert np.array_equal(a.readback_accumulation(), fr_a.accumulation)
+        a.set_constants(_consts(bunny, W, H, NR, 6, BUNNY_CAM))
+        a.render_samples(6, 2)
+        osc_a2 = helpers.oracle_scene(bunny, pt.default_lights(), pt.load_blue_noise())
+        for frame in (6, 7):
+            oracle.render_frame(osc_a2, fr_a, _consts(bunny, W, H, NR, frame, BUNNY_CAM), mode=mode)
+        a.render_flush()
+        assert np.array_equal(a.readback_accumulation(), fr_a.accumulation)
+        b.render_flush()
+        _compare(b, fr_b, live_slots_only=True)
+        b.render_samples(6, 4)                          # left in flight when the context goes
+    finally:
+        b.close()
+        a.close()
+
+
 def test_cornell_box_512_four_bounces(gpu_ctx, oracle_lib):
     """The plumbing configuration: Cornell box (stand-in geometry, 34 triangles) at 512 x 512 with 4 bounces from the
     reference's default camera; every buffer equals the oracle's after two frames."""
