@@ -831,6 +831,7 @@ PT_API int pt_set_constants(PtContext* ctx, const PtShaderConstants* c)
     if (ctx->train.live) {      /* frames in a kept train are finished under the constants they entered with; a new frameIndex alone changes nothing for them */
         PtShaderConstants was = ctx->consts, now = *c;
         was.frameIndex = now.frameIndex = 0;
+        memset(was._pad0, 0, sizeof was._pad0); memset(now._pad0, 0, sizeof now._pad0); was._pad1 = now._pad1 = 0;      /* nothing reads the padding */
         if (memcmp(&was, &now, sizeof was)) if (int rc = settle(ctx)) return rc;
     }
     ctx->consts = *c; ctx->haveConsts = true;
