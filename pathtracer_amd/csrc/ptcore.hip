@@ -440,7 +440,9 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
         a.overflowEntries = ctx->overflowEntries;
     }
     a.flagList = flag; a.flagCount = ctr;
-    a.refillMin = (uint32_t)refill_min(ctx, shape);
+    /* a step of this walk is half again as long as the near-first walk's, so idle lanes cost more and are refilled sooner:
+       batches at 4 / 8 / 12 / 16 / 24 idle lanes -> 2 094 / 2 170 / 2 165 / 2 138 / 2 067 Mrays/s */
+    a.refillMin = (uint32_t)(MODE == MODE_RAYS && !ctx->userRefill ? 10 : refill_min(ctx, shape));
     dim3 grid(blocks), block(PT_BLOCK);
     if (count) hipLaunchKernelGGL((k_trace_cert<MODE, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_trace_cert<MODE, false>), grid, block, 0, stream, a);
