@@ -27,6 +27,14 @@ def test_abi_exports_every_declared_symbol():
     assert b"gfx950" in core._load().pt_version()
 
 
+def test_option_numbers_of_the_binding_are_the_header_s():
+    hdr = open(os.path.join(ROOT, "include", "ptcore.h")).read()
+    in_header = {name: int(val) for name, val in re.findall(r"^\s+PT_OPT_(\w+)\s*=\s*(\d+)", hdr, re.M)}      # the enum's own lines
+    assert len(in_header) >= 17 and len(set(in_header.values())) == len(in_header)
+    in_binding = {k[4:]: v for k, v in vars(core).items() if k.startswith("OPT_") and isinstance(v, int)}
+    assert in_binding == in_header
+
+
 def test_context_needs_a_gpu_and_says_so():
     import torch
     if torch.cuda.is_available():
