@@ -109,12 +109,33 @@ struct TraceArgs {
  * own.  issue_ray returns false for a dead job (nothing was loaded). */
 struct RayWords { float4 w0, w1; uint32_t tag; };
 
+/* The rays of a batch come in and its hits go out once per launch, gigabytes of them beside the traversal records the L2
+ * is there for: their loads and stores are marked non-temporal so that the caches do not keep them (a 2^26-ray batch:
+ * 24.4 -> 24.0 ms with both; the store alone gains half of it, the loads alone nothing).  The path tracer's passes keep
+ * plain accesses: what they write the next pass reads.  PT_STREAM_NT=0 builds the plain accesses for comparison. */
+#ifndef PT_STREAM_NT
+#define PT_STREAM_NT 1
+#endif
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 stream_load(const float4* p)
+{
+    if (!NT) return *p;
+    nt_f4 v = __builtin_nontemporal_load((const nt_f4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool NT> __device__ __forceinline__ void stream_store(float4* p, float4 o)
+{
+    if (!NT) { *p = o; return; }
+    nt_f4 v = { o.x, o.y, o.z, o.w };
+    __builtin_nontemporal_store(v, (nt_f4*)p);
+}
+
 template <int MODE>
 __device__ __forceinline__ bool issue_ray(const TraceArgs& a, uint64_t id, RayWords& w)
 {
     if (MODE == MODE_RAYS) {
         const float4* p = (const float4*)(a.rays + id);          /* id: the ray's own index */
-        w.w0 = p[0]; w.w1 = p[1]; w.tag = 0;
+        w.w0 = stream_load<PT_STREAM_NT>(p); w.w1 = stream_load<PT_STREAM_NT>(p + 1); w.tag = 0;
         return true;
     } else if (MODE == MODE_JOBS) {
         uint32_t slot = a.jobs[id];
@@ -167,7 +188,7 @@ __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, ui
         float4 o;
         o.x = t;
         o.y = __int_as_float(hit ? i1 : -1); o.z = __int_as_float(hit ? i2 : -1); o.w = __int_as_float(hit ? i3 : -1);
-        *(float4*)(a.hits + id) = o;
+        stream_store<PT_STREAM_NT>((float4*)(a.hits + id), o);
     } else if (MODE == MODE_JOBS) {
         uint4 o0, o1;
         o0.x = __float_as_uint(t);
