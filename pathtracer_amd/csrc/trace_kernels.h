@@ -130,12 +130,12 @@ template <bool NT> __device__ __forceinline__ void stream_store(float4* p, float
     __builtin_nontemporal_store(v, (nt_f4*)p);
 }
 
-template <int MODE>
+template <int MODE, bool NT = (PT_STREAM_NT != 0)>
 __device__ __forceinline__ bool issue_ray(const TraceArgs& a, uint64_t id, RayWords& w)
 {
     if (MODE == MODE_RAYS) {
         const float4* p = (const float4*)(a.rays + id);          /* id: the ray's own index */
-        w.w0 = stream_load<PT_STREAM_NT>(p); w.w1 = stream_load<PT_STREAM_NT>(p + 1); w.tag = 0;
+        w.w0 = stream_load<NT>(p); w.w1 = stream_load<NT>(p + 1); w.tag = 0;
         return true;
     } else if (MODE == MODE_JOBS) {
         uint32_t slot = a.jobs[id];
@@ -180,7 +180,7 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint64_t id, RayReg
     return true;
 }
 
-template <int MODE>
+template <int MODE, bool NT = (PT_STREAM_NT != 0)>
 __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, uint32_t tag, bool hit, float t, int32_t i1, int32_t i2, int32_t i3,
                                              float alpha, float beta, float gamma, uint32_t origBvhId)
 {
@@ -188,7 +188,7 @@ __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, ui
         float4 o;
         o.x = t;
         o.y = __int_as_float(hit ? i1 : -1); o.z = __int_as_float(hit ? i2 : -1); o.w = __int_as_float(hit ? i3 : -1);
-        stream_store<PT_STREAM_NT>((float4*)(a.hits + id), o);
+        stream_store<NT>((float4*)(a.hits + id), o);
     } else if (MODE == MODE_JOBS) {
         uint4 o0, o1;
         o0.x = __float_as_uint(t);
@@ -1013,6 +1013,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
  */
 #ifndef PT_CERT_SLACK
 #define PT_CERT_SLACK 0x1p-7f
+#ifndef PT_CERT_NT_LOAD
+#define PT_CERT_NT_LOAD false
+#endif
+#ifndef PT_CERT_NT_STORE
+#define PT_CERT_NT_STORE (PT_STREAM_NT != 0)
+#endif
 #endif
 __device__ __forceinline__ h16 round_down_h16(float v)
 {
@@ -1090,12 +1096,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
 
     auto flag_ray = [&]() { a.flagList[atomicAdd(a.flagCount, 1u)] = (uint32_t)id; };
     auto issue = [&](uint64_t rid, RayWords& w) -> bool {
-        if (MODE != MODE_MIXED) return issue_ray<MODE>(a, rid, w);
+        if (MODE != MODE_MIXED) return issue_ray<MODE, PT_CERT_NT_LOAD>(a, rid, w);
         freshShadow = rid >= numJobs;
         return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
     };
     auto store = [&](bool h) {
-        if (MODE != MODE_MIXED) store_result<MODE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
+        if (MODE != MODE_MIXED) store_result<MODE, PT_CERT_NT_STORE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
         else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, r.max_t, -1, -1, -1, 0, 0, 0, 0u);
         else store_result<MODE_JOBS>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
     };
