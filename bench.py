@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--tris", type=int, default=5_800_000)
     ap.add_argument("--rays", type=int, default=1 << 26)
     ap.add_argument("--traversal", type=int, default=-1, help="-1 = library default")
+    ap.add_argument("--layout", type=int, default=-1, help="record layout (PT_OPT_RECORD_LAYOUT); -1 = library default")
     ap.add_argument("--scene", type=str, default="", help="a real SanMiguel.ply; accepted only if its sha256 is the oid of the reference's Git-LFS stub")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
@@ -113,6 +114,8 @@ def main():
     nodes, ridx, depth = pt.build_bvh(pos, idx, threads)
     t2 = time.time()
     ctx = pt.PathTracer(device)
+    if args.layout >= 0:
+        ctx.set_option(core.OPT_RECORD_LAYOUT, args.layout)      # read when the scene is flattened
     ctx.upload_scene(pos, aux, ridx, nodes, pt.default_lights(), pt.load_blue_noise())
     if args.traversal >= 0:
         ctx.set_option(core.OPT_TRAVERSAL, args.traversal)
