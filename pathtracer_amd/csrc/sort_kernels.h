@@ -18,7 +18,7 @@
 #include "../../include/ptcore.h"
 
 #define PT_SORT_BINS 4096
-#define PT_SORT_TILE 32768
+#define PT_SORT_TILE 32768       /* 16384 and 49152 measure the same, 8192 is slower */
 #define PT_SORT_BLOCK 1024
 
 __device__ __forceinline__ uint32_t spread4(uint32_t v)      /* bits 0..3 of v to bits 0,3,6,9 */
@@ -86,7 +86,19 @@ __device__ __forceinline__ void bin_scatter_tile(uint64_t n, const uint16_t* key
     const uint64_t base = (uint64_t)blockIdx.x * PT_SORT_TILE;
     if (base >= n) return;                                /* the same for the whole workgroup */
     const uint32_t count = (uint32_t)((n - base < PT_SORT_TILE) ? n - base : PT_SORT_TILE);
-    for (uint32_t k = t; k < count; k += PT_SORT_BLOCK) atomicAdd(&hist[keys[base + k]], 1u);
+    /* The thread's keys are fetched once, all loads in flight together, and kept in registers for both passes over them:
+       a loop that feeds each loaded key to an LDS atomic pays the memory latency turn by turn, and with one workgroup per
+       CU (the LDS it needs) there is nobody else to hide it (0.54 -> 0.42 ms for 2^26 rays). */
+    constexpr int KEYS = PT_SORT_TILE / PT_SORT_BLOCK;
+    constexpr uint32_t NO_KEY = 0xFFFFu;                  /* keys are below PT_SORT_BINS */
+    uint32_t key[KEYS];
+#pragma unroll
+    for (int j = 0; j < KEYS; j++) {
+        const uint32_t k = (uint32_t)t + (uint32_t)j * PT_SORT_BLOCK;
+        key[j] = k < count ? (uint32_t)keys[base + k] : NO_KEY;
+    }
+#pragma unroll
+    for (int j = 0; j < KEYS; j++) if (key[j] != NO_KEY) atomicAdd(&hist[key[j]], 1u);
     __syncthreads();
     /* exclusive scan of the tile histogram: four consecutive bins per thread */
     uint32_t c[per], s = 0;
@@ -107,8 +119,11 @@ __device__ __forceinline__ void bin_scatter_tile(uint64_t n, const uint16_t* key
         run += c[k];
     }
     __syncthreads();
-    for (uint32_t k = t; k < count; k += PT_SORT_BLOCK) local[atomicAdd(&hist[keys[base + k]], 1u)] = (uint16_t)k;
+#pragma unroll
+    for (int j = 0; j < KEYS; j++)
+        if (key[j] != NO_KEY) local[atomicAdd(&hist[key[j]], 1u)] = (uint16_t)((uint32_t)t + (uint32_t)j * PT_SORT_BLOCK);
     __syncthreads();
+#pragma unroll 8
     for (uint32_t pos = t; pos < count; pos += PT_SORT_BLOCK) {
         const uint32_t k = local[pos];
         order[gbase[keys[base + k]] + pos] = (uint32_t)(base + k);
