@@ -15,12 +15,14 @@ SanMiguel.ply is a Git-LFS pointer stub in the reference checkout, so the scene 
 stand-in pathtracer_amd.scenes.san_miguel_like (5.8 M triangles); config.workload says so.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     - algorithmic bytes per launch / mean kernel time (HIP events on the kernel's stream)
-                 against the 8 TB/s HBM peak,
+  roofline     - bytes that crossed the fabric per launch (rocprofv3 counters of this same command, kept in
+                 profiles/traffic.json) / mean kernel time (HIP events on the kernel's stream) against the 8 TB/s
+                 HBM peak; the algorithmic bytes the walk asks for are reported beside it (requested_GBps),
   cpu_baseline - the CPU oracle in reference-faithful mode timed on a bounded sample of the same
                  rays on this box's host cores (N = 1 only),
-  extra        - spp/s of the full wavefront path tracer at 1080p x 8 bounces on the SanMiguel and sponza
-                 stand-ins, measured outside the timed region, for context.
+  extra        - measured outside the timed region, for context: the certified and any-hit walks on the same rays, spp/s
+                 of the full wavefront path tracer (1080p and 4K x 8 bounces on the SanMiguel and sponza stand-ins,
+                 CBbunny primary + 1 bounce); with N > 1 the sample-partitioned render and its all-reduce instead.
 """
 import argparse
 import json
