@@ -295,15 +295,18 @@ def main():
     printed = threading.Lock()
 
     def emit(note=None):
+        """Prints the line once; False if another thread has already taken that on."""
         if not printed.acquire(blocking=False):
-            return
+            return False
         if rank == 0:
             if note:
                 result.setdefault("extra", {})["error"] = note
             print(json.dumps(result), flush=True)
+        return True
 
     def give_up():
-        emit(f"context numbers for N > 1 did not finish within {extra_timeout:.0f} s; the headline above was measured before them")
+        if not emit(f"context numbers for N > 1 did not finish within {extra_timeout:.0f} s; the headline above was measured before them"):
+            return      # the main thread is printing its line: it got there after all
         sys.stderr.flush()
         os._exit(0)
 
