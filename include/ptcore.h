@@ -257,9 +257,10 @@ enum {
     PT_OPT_RESEED         = 3,   /* 0 = seed the LCG only after a clear (launch.comp:49-50, default);
                                     1 = reseed every frame (needed when frames are split over GPUs) */
     PT_OPT_PERSIST_BLOCKS = 4,   /* workgroups (256 lanes) per CU of the persistent traversal kernels; unset: 5 for a batch
-                                    traced as given, 6 for an ordered batch, 3 for the passes of the path tracer */
+                                    traced as given, 6 for an ordered batch (7 for its near-first walk over 64 B records, whose
+                                    66 VGPRs let a SIMD hold seven wavefronts), 3 for the passes of the path tracer */
     PT_OPT_REFILL_MIN     = 5,   /* a wavefront refills its idle lanes once this many of its 64 are idle; unset: 36, 24
-                                    and 12 for the same three uses */
+                                    (26 and, for any-hit rays, 32 where the launch is seven wide) and 12 for the same three uses */
     PT_OPT_CLAIM_CHUNK    = 6,   /* ray ids a wavefront takes from the global counter at a time: 0 = chosen from the
                                     ray count (64..128), else 64..1024 in steps of 64 */
     PT_OPT_RECORD_LAYOUT  = 8,   /* read by pt_scene_upload: 0 = 64 B records; 1 = 48 B records when every box

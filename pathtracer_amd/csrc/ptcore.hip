@@ -288,7 +288,7 @@ int blocks_per_cu(PtContext* c, int shape)
     return shape == SHAPE_FRAME && small_scene(c) ? 2 : d[shape];
 }
 int refill_min(PtContext* c, int shape) { static const int d[3] = { 36, 24, 12 }; return c->userRefill ? c->optRefillMin : d[shape]; }
-int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 6 || c->userBlocks ? c->optBlocksPerCU : 6); }   /* sizes the spill areas */
+int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 7 || c->userBlocks ? c->optBlocksPerCU : 7); }   /* sizes the spill areas: the widest default launch is seven workgroups per CU */
 
 /* Spill areas of the LDS stacks: one per traversal kernel that can be running at a time, that is two per pipe
  * (closest-hit pass and shadow pass side by side). */
@@ -361,6 +361,14 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
        changes; 48 B records and trees whose boxes do not nest get the reference-order walk throughout */
     int trav = ctx->optTraversal;
     if (trav == 3) trav = ANYHIT ? 2 : 1;
+    /* The near-first walk over 64 B records takes 66 VGPRs, so a SIMD holds seven of its wavefronts: an ordered batch runs
+       seven workgroups per CU wide and refills a little later (closest hit, workgroups x idle lanes -> ms per 2^26 rays:
+       6 x 20 / 24 / 28: 24.89 / 24.98 / 25.29; 7 x 20 / 24 / 26 / 28 / 30: 24.94 / 24.63 / 24.58 / 24.62 / 24.68; any hit:
+       6 x 24 19.73, 7 x 24 / 28 / 32 19.93 / 19.64 / 19.52).  The other walks keep more registers and the table's shape. */
+    if (MODE == MODE_RAYS && shape == SHAPE_ORDERED_BATCH && trav == 2 && !ctx->dTreelets && !ctx->compact && !(fixed && fixed->maxBlocks)) {
+        if (!ctx->userBlocks) grid = dim3(ctx->numCUs * 7);
+        if (!ctx->userRefill) a.refillMin = ANYHIT ? 32u : 26u;
+    }
     if (trav == 0) {
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
