@@ -63,6 +63,30 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# what the N > 1 context numbers were doing when the watchdog fired: set before every collective and every library call that
+# may block on a peer, printed with the time-out so that the one record names the step that hung
+STAGE = ["start"]
+
+
+def stage(name):
+    STAGE[0] = name
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: starts N ranks of this same command line under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) as a child process and returns its exit status; rank 0's JSON line
+    goes to this process's stdout.  The parent never initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no launcher in the environment, starting the ranks: " + " ".join(cmd))
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,16 +102,30 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        log("--gpus must be at least 1")
+        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: this process becomes the launcher.  Nothing here has touched the GPU or imported
+        # torch, and the ranks are children (one per GPU, torch.distributed.run), never an exec of this process.
+        sys.exit(spawn_ranks(args.gpus))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        # a line for N GPUs measured on another number of ranks would be filed under the wrong N
+        log(f"error: WORLD_SIZE={world} but --gpus {args.gpus}: start {args.gpus} ranks (or run without a launcher, which starts them)")
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
     # PT_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        log(f"error: {world} ranks but {torch.cuda.device_count()} GPUs visible; RCCL needs one GPU per rank "
+            f"(PT_BENCH_BACKEND=gloo rehearses the rank logic with ranks sharing devices)")
+        sys.exit(2)
     device = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
     torch.cuda.set_device(device)
     if world > 1:
@@ -290,7 +328,7 @@ def main():
     # From here on nothing is timed for the headline, and with N > 1 every step is a collective: a rank that dies or hangs
     # in one would hold the others, and the measured line with them.  A watchdog therefore ends the process once the context
     # numbers have taken longer than PT_BENCH_EXTRA_TIMEOUT seconds (default 300): rank 0 prints the line it has, with the
-    # time-out named under extra, and every rank leaves with os._exit (no exec, no wait on a peer).
+    # time-out and the stage it struck in named under extra, and every rank leaves with os._exit(3) (no exec, no wait on a peer).
     import threading
     printed = threading.Lock()
 
@@ -305,10 +343,11 @@ def main():
         return True
 
     def give_up():
-        if not emit(f"context numbers for N > 1 did not finish within {extra_timeout:.0f} s; the headline above was measured before them"):
+        if not emit(f"context numbers for N > 1 did not finish within {extra_timeout:.0f} s (stage: {STAGE[0]}); the headline above was measured before them"):
             return      # the main thread is printing its line: it got there after all
+        log(f"rank {rank}: watchdog: timed out after {extra_timeout:.0f} s in stage '{STAGE[0]}'")
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(3)     # a time-out is a failure: the harness must see a non-zero status, whatever the line says
 
     extra_timeout = float(os.environ.get("PT_BENCH_EXTRA_TIMEOUT", "300"))
     watchdog = None
@@ -329,6 +368,7 @@ def main():
     try:
         ctx.close()
         if world > 1:
+            stage("final torch barrier")
             dist.barrier()
     finally:
         if watchdog:
@@ -518,6 +558,7 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
     NR = 8
     dev = "cuda" if backend == "nccl" else "cpu"
     ok, err = 1, ""
+    stage(f"{W}x{H}: set-up and warm-up render")
     try:
         ctx.set_option(core.OPT_RESEED, 1)
         ctx.resize(W, H, NR)
@@ -527,11 +568,14 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
         ctx.synchronize()
     except Exception as e:
         ok, err = 0, str(e)
+    stage(f"{W}x{H}: torch all_reduce of the set-up flag")
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         return {"error": err or "another rank failed during set-up"}
+    stage(f"{W}x{H}: torch barrier before the timed render")
     dist.barrier()
+    stage(f"{W}x{H}: rendering this rank's frames (pt_render_samples)")
     t = time.perf_counter()
     try:
         ctx.render_samples(1000 + rank * nf, nf)
@@ -539,6 +583,7 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
         t_render = time.perf_counter() - t
     except Exception as e:
         ok, err, t_render = 0, str(e), 0.0
+    stage(f"{W}x{H}: torch all_reduce of the render flag")
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
@@ -546,6 +591,7 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
     # the library's own RCCL entry points (what a C++ host without torch calls) on the same buffer first: the sum is taken,
     # read back and the buffer restored, then torch's all-reduce runs on it and the two results are compared
     native = native_allreduce_check(ctx, rank, world, backend, dev)
+    stage(f"{W}x{H}: torch all_reduce deciding whether there is a native result")
     # whether there is a native result to compare is decided by all ranks together: the comparison below ends in a collective
     have = torch.tensor([0 if native.get("result") is None else 1], dtype=torch.int32, device=dev)
     dist.all_reduce(have, op=dist.ReduceOp.MIN)
@@ -553,9 +599,11 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
         native["result"] = None
         native.setdefault("error", "another rank has no native result")
     t_ar = time.perf_counter()
+    stage(f"{W}x{H}: torch all_reduce of the accumulation ({16 * W * H} bytes)")
     distributed.allreduce_accumulation_torch(ctx)       # raises on every rank or on none: same library, same buffer size
     dt = time.perf_counter() - t - native["seconds_spent"]
     t_torch = time.perf_counter() - t_ar
+    stage(f"{W}x{H}: torch all_reduce (max) of the times")
     tt = torch.tensor([dt, t_render], dtype=torch.float64, device=dev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt, t_render = float(tt[0].item()), float(tt[1].item())
@@ -567,6 +615,7 @@ def path_tracer_spp_partitioned(ctx, num_triangles, num_nodes, rank, world, back
         native["equals_torch_allreduce"] = bool(same)
         native["max_abs_difference"] = float(np.abs(native["result"] - acc).max())
         native["torch_allreduce_s"] = round(t_torch, 4)
+        stage(f"{W}x{H}: torch all_reduce of the native-equals-torch verdict")
         agree = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(agree, op=dist.ReduceOp.MIN)
         native["equals_torch_allreduce_on_every_rank"] = bool(int(agree.item()))
@@ -599,18 +648,23 @@ def native_allreduce_check(ctx, rank, world, backend, dev):
                 uid = torch.from_numpy(core.comm_unique_id().copy()).to(dev)
             except Exception as e:
                 ok, out["error"] = 0, str(e)
+        stage("native RCCL: torch broadcast of the id flag")
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.broadcast(flag, 0)
         if int(flag.item()) == 0:
             out.setdefault("error", "rank 0 could not make a communicator id")
             out["seconds_spent"] = time.perf_counter() - t0
             return out
+        stage("native RCCL: torch broadcast of the communicator id")
         dist.broadcast(uid, 0)
         before = ctx.readback_accumulation()
+        stage("native RCCL: pt_comm_init (ncclCommInitRank)")
         ctx.comm_init(rank, world, uid.cpu().numpy())            # collective: every rank is here
         ctx.synchronize()
+        stage("native RCCL: torch barrier after pt_comm_init")
         dist.barrier()
         t = time.perf_counter()
+        stage("native RCCL: pt_allreduce_accumulation (ncclAllReduce)")
         ctx.allreduce_accumulation()
         ctx.synchronize()
         out["allreduce_s"] = round(time.perf_counter() - t, 4)

@@ -418,17 +418,23 @@ PT_API int pt_write_ppm(const char* path, uint32_t width, uint32_t height, const
  * stats[3] - num_rays is the number of rays that took the second walk. */
 PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit,
                          PtHit* d_hits, uint64_t* stats);
-/* pt_trace_rays for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same rays in, same hits out, byte for byte, but
+/* pt_trace_rays for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc).
+ * No counterpart in the reference.  Same rays in, same hits out, byte for byte, but
  * the call allocates and frees nothing: the ray-id counters, the ordering pass's bins, keys and order, the certified
  * walk's list and the spill area of the traversal stacks all live in one static device array of 52 MiB that every GPU
- * the library runs on holds from the first pt_ctx_create on it until the process ends.  Limits: at most 2^21
+ * the library runs on holds from the first pt_ctx_create on it until the process ends (part of the library's code object:
+ * a process pays for it on every GPU it creates a context on, whether or not it ever calls this).  Limits: at most 2^21
  * (2 097 152) rays per call (-1 beyond that), and a tree whose stack need beyond the 12 entries kept in LDS fits the
  * array's 32 MiB spill area with at least one workgroup per CU (-1 otherwise; a deep tree runs with fewer workgroups
  * than pt_trace_rays would use).  A walk over 64 B or 48 B records needs one stack entry per level of the tree, a walk
  * over treelet records three per two levels: on a 256-CU part that is a depth of 76, or of 50 with
- * PT_OPT_RECORD_LAYOUT = 2.  All calls on one GPU share that GPU's array, from
- * whatever context: calls that overlap in time on one GPU race; calls on one context are ordered on its stream. */
+ * PT_OPT_RECORD_LAYOUT = 2.  All calls on one GPU share that GPU's array, from whatever context.  Calls from one
+ * process take turns on it: every call makes its stream wait for an event recorded behind the previous call's last
+ * launch on that GPU (the event is made at pt_ctx_create), so contexts on different streams may call back to back
+ * without a host synchronisation.  Calls from different PROCESSES do not share the array (each process has its own
+ * copy).  The hand-over uses stream waits and an event record, which a stream under HIP graph capture does not take
+ * from outside the capture: the call is not for use under capture.  -2 if the array's address could not be resolved
+ * at pt_ctx_create (the reason is in pt_last_error). */
 PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays, int any_hit, PtHit* d_hits);
 /* Same with HOST pointers: copies in, traces, copies out. */
 PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t num_rays, int any_hit,

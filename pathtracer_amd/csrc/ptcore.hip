@@ -84,6 +84,11 @@ static __device__ __align__(256) unsigned char scratch[NA_TOTAL];
 namespace {
 enum { PT_MAX_DEVICES = 64 };
 unsigned char* g_scratchPtr[PT_MAX_DEVICES] = { nullptr };     /* device address of `scratch` on each device, once resolved */
+/* Recorded behind the last launch of every pt_trace_rays_noalloc call on the device, waited for by the next call's stream
+ * before it touches the array: calls from different contexts (different streams) of one process then take turns on the
+ * device's one array instead of overwriting each other's counters, bins, order and lists.  Made with the address, at
+ * pt_ctx_create, so that the call itself creates nothing. */
+hipEvent_t g_scratchEvent[PT_MAX_DEVICES] = { nullptr };
 std::mutex g_scratchMutex;
 
 /* Device address of this device's copy of the scratch array; the device must be current.  nullptr + message on failure. */
@@ -95,6 +100,11 @@ unsigned char* resolve_scratch(int device, std::string& err)
     unsigned char* ptr = nullptr;
     hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !ptr) { err = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e); return nullptr; }
+    if (!g_scratchEvent[device] && (e = hipEventCreateWithFlags(&g_scratchEvent[device], hipEventDisableTiming)) != hipSuccess) {
+        g_scratchEvent[device] = nullptr;
+        err = std::string("hipEventCreate for the scratch array: ") + hipGetErrorString(e);
+        return nullptr;
+    }
     g_scratchPtr[device] = ptr;
     return ptr;
 }
@@ -201,6 +211,7 @@ struct PtContext {
     float lastMs = 0.0f; bool evPending = false;
     void* comm = nullptr;
     unsigned char* scratchPtr = nullptr;    /* this device's copy of the scratch array (pt_trace_rays_noalloc) */
+    std::string scratchErr;                 /* why scratchPtr is null, if it is */
 
     int fail(int code, const std::string& m) { err = m; return code; }
 };
@@ -365,8 +376,12 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
        seven workgroups per CU wide and refills a little later (closest hit, workgroups x idle lanes -> ms per 2^26 rays:
        6 x 20 / 24 / 28: 24.89 / 24.98 / 25.29; 7 x 20 / 24 / 26 / 28 / 30: 24.94 / 24.63 / 24.58 / 24.62 / 24.68; any hit:
        6 x 24 19.73, 7 x 24 / 28 / 32 19.93 / 19.64 / 19.52).  The other walks keep more registers and the table's shape. */
-    if (MODE == MODE_RAYS && shape == SHAPE_ORDERED_BATCH && trav == 2 && !ctx->dTreelets && !ctx->compact && !(fixed && fixed->maxBlocks)) {
-        if (!ctx->userBlocks) grid = dim3(ctx->numCUs * 7);
+    if (MODE == MODE_RAYS && shape == SHAPE_ORDERED_BATCH && trav == 2 && !ctx->dTreelets && !ctx->compact) {
+        if (!ctx->userBlocks) {
+            int wide = ctx->numCUs * 7;
+            if (fixed && fixed->maxBlocks && wide > fixed->maxBlocks) wide = fixed->maxBlocks;      /* a fixed spill area bounds the launch */
+            grid = dim3(wide);
+        }
         if (!ctx->userRefill) a.refillMin = ANYHIT ? 32u : 26u;
     }
     if (trav == 0) {
@@ -602,9 +617,9 @@ PT_API int pt_ctx_create(int device_id, PtContext** out)
         return -10;
     }
     memset(&ctx->consts, 0, sizeof(ctx->consts));
-    /* this device's copy of the static scratch array: its address is asked for here, with the device current */
-    ctx->scratchPtr = resolve_scratch(device_id, g_createError);
-    if (!ctx->scratchPtr) { pt_ctx_destroy(ctx); return -10; }
+    /* this device's copy of the static scratch array: its address is asked for here, with the device current.  A host
+       that never calls pt_trace_rays_noalloc does not need it: a failure is kept for that call to report (-2) */
+    ctx->scratchPtr = resolve_scratch(device_id, ctx->scratchErr);
     *out = ctx;
     return 0;
 }
@@ -1558,7 +1573,7 @@ PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t n
     if (num_rays > NA_MAX_RAYS) return ctx->fail(-1, "pt_trace_rays_noalloc: at most 2^21 (2 097 152) rays per call; larger batches need pt_trace_rays");
     if (num_rays == 0) return 0;
     unsigned char* base = ctx->scratchPtr;
-    if (!base) return ctx->fail(-2, "pt_trace_rays_noalloc: the scratch array's device address was not resolved at pt_ctx_create");
+    if (!base) return ctx->fail(-2, "pt_trace_rays_noalloc: the scratch array's device address was not resolved at pt_ctx_create (" + ctx->scratchErr + ")");
     BatchScratch sc;
     /* the spill area holds (tree depth - LDS part) entries per lane of the launch: the launch takes as many workgroups
        as fit, up to its usual number; a tree too deep for even one workgroup per CU is refused */
@@ -1578,10 +1593,20 @@ PT_API int pt_trace_rays_noalloc(PtContext* ctx, const PtRay* d_rays, uint64_t n
     sc.sortKeys = (uint16_t*)(base + NA_OFF_KEYS);
     sc.flagList = (uint32_t*)(base + NA_OFF_FLAGS);
     sc.spill = (uint2*)(base + NA_OFF_SPILL);
+    /* One array per GPU, any number of contexts: this call's work starts when the last call's work on this GPU has ended,
+       whatever stream that ran on, and the host side of the hand-over (wait, queue, record) is one critical section. */
+    std::lock_guard<std::mutex> lk(g_scratchMutex);
+    hipEvent_t turn = g_scratchEvent[ctx->device];
+    HIPCHK(hipStreamWaitEvent(ctx->stream, turn, 0));          /* an event never recorded holds nothing up */
     /* the array keeps what the last call on this GPU left: counters and bin counts start from zero (the rest is
        written before it is read) */
     HIPCHK(hipMemsetAsync(base + NA_OFF_CTR, 0, NA_OFF_ORDER - NA_OFF_CTR, ctx->stream));
-    return trace_batch(ctx, d_rays, num_rays, any_hit, d_hits, nullptr, sc);
+    const int rc = trace_batch(ctx, d_rays, num_rays, any_hit, d_hits, nullptr, sc);
+    /* recorded whether or not every launch was queued: what was queued must end before the next call starts */
+    hipError_t e = hipEventRecord(turn, ctx->stream);
+    if (rc) return rc;
+    if (e != hipSuccess) return ctx->fail(-10, std::string("hipEventRecord(scratch turn): ") + hipGetErrorString(e));
+    return 0;
 }
 
 PT_API int pt_trace_rays_host(PtContext* ctx, const PtRay* rays, uint64_t n, int any_hit, PtHit* hits, uint64_t* stats)

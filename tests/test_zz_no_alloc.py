@@ -88,3 +88,43 @@ def test_noalloc_on_a_second_context_and_scene(scene, bunny):
             d_rays.free(); d_a.free(); d_b.free()
     finally:
         a.close(); b.close()
+
+
+def test_noalloc_calls_of_two_contexts_back_to_back_without_a_host_sync(scene, bunny):
+    """Two contexts on one GPU run on different non-blocking streams and share the GPU's one array.  Calls queued back to
+    back from both, with no host synchronisation in between and batches of very different sizes, take turns on the array
+    (each call's stream waits for the event recorded behind the previous call on that GPU): every call's hits equal
+    pt_trace_rays', and the certified walk - whose list of rays for the second pass and whose ordering live in the array -
+    is among them."""
+    a, b = pt.PathTracer(0), pt.PathTracer(0)
+    bufs = []
+    try:
+        helpers.upload(a, scene)
+        helpers.upload(b, bunny)
+        plan = []
+        for ctx, model, n, trav in ((a, scene, MAX_RAYS, core.TRAVERSAL_FLAT_ORDERED), (b, bunny, 3_001, core.TRAVERSAL_CERTIFIED),
+                                    (a, scene, 1_500_000, core.TRAVERSAL_CERTIFIED), (b, bunny, 40_000, core.TRAVERSAL_FLAT_ORDERED)):
+            ctx.set_option(core.OPT_SORT_RAYS, 1)
+            d_rays, d_ref, d_out = ctx.alloc(n * 32), ctx.alloc(n * 16), ctx.alloc(n * 16)
+            bufs += [d_rays, d_ref, d_out]
+            if model is scene:
+                ctx.generate_rays(d_rays, n, seed=7 + n)
+            else:
+                d_rays.from_host(helpers.random_rays(model["nodes"][0]["a"], model["nodes"][0]["b"], n, seed=n))
+            ctx.set_option(core.OPT_TRAVERSAL, trav)
+            ctx.trace_rays_device(d_rays, n, d_ref)
+            plan.append((ctx, d_rays, d_ref, d_out, n, trav))
+        a.synchronize(); b.synchronize()
+        for rounds in range(3):
+            for ctx, d_rays, d_ref, d_out, n, trav in plan:            # a, b, a, b: no host sync anywhere in the loop
+                if ctx.get_option(core.OPT_TRAVERSAL) != trav:
+                    ctx.set_option(core.OPT_TRAVERSAL, trav)
+                ctx.trace_rays_device_noalloc(d_rays, n, d_out)
+        a.synchronize(); b.synchronize()
+        for ctx, d_rays, d_ref, d_out, n, trav in plan:
+            ref, out = d_ref.to_host(pt.HIT_DT, n), d_out.to_host(pt.HIT_DT, n)
+            assert np.array_equal(ref.view(np.uint8), out.view(np.uint8)), f"{int((ref != out).sum())} of {n} hits differ (traversal {trav})"
+    finally:
+        for x in bufs:
+            x.free()
+        a.close(); b.close()
