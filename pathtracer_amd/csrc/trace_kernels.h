@@ -1059,6 +1059,70 @@ __device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float 
     boundL = __builtin_fmaf(-fabsf(eL), PT_CERT_SLACK, eL); boundR = __builtin_fmaf(-fabsf(eR), PT_CERT_SLACK, eR);
 }
 
+/* The same lower bounds from the box test's own fp16 values (PT_CERT_BOUND16, default): box_pair with, per axis, the
+ * near slab distance min(t0, t1) it computes anyway, less a bound E of everything that separates that fp16 value from the
+ * exact (a - o) / d, (b - o) / d of the builder's fp32 box [a, b]:
+ *
+ *   digest      ha = f16(a - c):  |ha - (a - c)| <= |a - c| (2^-11 + 2^-23), or 2^-25 below the normal range;
+ *   origin      nox = f16(c - o): the same for c - o;
+ *   sum         s = ha + nox in fp16: one rounding, 2^-11 relative (fp16 sums below the normal range are exact);
+ *   direction   rx = f16(1 / d):  (1 / d)(1 + 2^-11 + 2^-24);
+ *   product     t = s rx in fp16: 2^-11 relative, or 2^-25 below the normal range.
+ *
+ * With W = max(|ha|, |hb|) + |nox| that is  |t - T| <= W |rx| 2^-9 (1 + 2^-8) + |rx| 2^-23 (1 + 2^-8) + 2^-25  for both
+ * planes of the slab, and  E = (W + 2^-12) k,  k = max(|rx| 2^-8, 2^-10) (a per-ray constant, exact in fp16), is at least
+ * twice that, which pays for the three roundings of E itself and for the one of near - E (a single fused operation: this
+ * is the bound's own arithmetic, not the reference's).  The entry distance is the largest near-plane distance, and the
+ * largest of the three lower bounds is a lower bound of it; where an axis yields NaN or -inf (0 x inf, an overflow) the
+ * IEEE maximum leaves it out, which keeps what is left a bound.  An fp16 tmin of +inf (a slab beyond the fp16 range)
+ * gives a bound of +inf: the reference's own `max_t > tmin` can never hold for that box either.  About 24 packed
+ * operations for both boxes where the fp32 bound takes 43 and 16 more to round its two results down to fp16 for the
+ * stack; and the bound is an fp16 value to begin with. */
+__device__ __forceinline__ void box_pair_bound(const RayRegs& r, h16x2 rx, h16x2 ry, h16x2 rz, h16x2 kx, h16x2 ky, h16x2 kz,
+                                               f32x2 cx, f32x2 cy, f32x2 cz, h16x2 ax, h16x2 ay, h16x2 az, h16x2 bx, h16x2 by, h16x2 bz,
+                                               bool& sL, bool& sR, float& tminL, float& tminR, h16x2& bound)
+{
+    const h16x2 pad = { (h16)0x1p-12f, (h16)0x1p-12f };
+    auto habs = [](h16x2 v) { return as_h2(__builtin_bit_cast(uint32_t, v) & 0x7FFF7FFFu); };
+    f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
+    h16x2 nox = __builtin_convertvector(dx, h16x2), noy = __builtin_convertvector(dy, h16x2), noz = __builtin_convertvector(dz, h16x2);
+    h16x2 t0 = (ax + nox) * rx, t1 = (bx + nox) * rx;
+    h16x2 near = __builtin_elementwise_min(t0, t1);
+    h16x2 tmin = near, tmax = __builtin_elementwise_max(t0, t1);
+    /* a <= c <= b, so -ha and hb are the magnitudes */
+    bound = __builtin_elementwise_fma(-((__builtin_elementwise_max(-ax, bx) + habs(nox)) + pad), kx, near);
+    t0 = (ay + noy) * ry; t1 = (by + noy) * ry;
+    near = __builtin_elementwise_min(t0, t1);
+    tmin = __builtin_elementwise_max(tmin, near);
+    tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
+    bound = __builtin_elementwise_max(bound, __builtin_elementwise_fma(-((__builtin_elementwise_max(-ay, by) + habs(noy)) + pad), ky, near));
+    t0 = (az + noz) * rz; t1 = (bz + noz) * rz;
+    near = __builtin_elementwise_min(t0, t1);
+    tmin = __builtin_elementwise_max(tmin, near);
+    tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
+    bound = __builtin_elementwise_max(bound, __builtin_elementwise_fma(-((__builtin_elementwise_max(-az, bz) + habs(noz)) + pad), kz, near));
+    const float fminL = (float)tmin.x, fminR = (float)tmin.y, fmaxL = (float)tmax.x, fmaxR = (float)tmax.y;
+    sL = (fmaxL > 0.0f || fminL > 0.0f) && fmaxL >= fminL && r.min_t < fmaxL;
+    sR = (fmaxR > 0.0f || fminR > 0.0f) && fmaxR >= fminR && r.min_t < fmaxR;
+    tminL = fminL; tminR = fminR;
+}
+/* k of box_pair_bound for one component of f16(1 / d), in both halves */
+__device__ __forceinline__ h16x2 bound_factor(h16 rcp)
+{
+    const h16 k = (h16)fmaxf(fabsf((float)rcp) * 0x1p-8f, 0x1p-10f);          /* exact: a power of two times an fp16 value */
+    return h16x2{ k, k };
+}
+/* The slack the walk allows the triangle test (see PT_CERT_SLACK), taken off both bounds in fp16: 9/8 of it, so that the
+ * rounding of this operation stays inside what was to be taken off. */
+__device__ __forceinline__ h16x2 bound_slack(h16x2 b)
+{
+    const h16x2 s = { (h16)(PT_CERT_SLACK * 1.125f), (h16)(PT_CERT_SLACK * 1.125f) };
+    return __builtin_elementwise_fma(-as_h2(__builtin_bit_cast(uint32_t, b) & 0x7FFF7FFFu), s, b);
+}
+#ifndef PT_CERT_BOUND16
+#define PT_CERT_BOUND16 1
+#endif
+
 /* MODE_RAYS, MODE_JOBS, or MODE_MIXED: a job list and, behind it, a shadow queue in one pool (see k_trace_flat).  A lane with
  * a shadow ray walks near child first with the reference's own culling and stops at the first hit: nothing about an any-hit
  * verdict depends on the order, so there is nothing to certify. */
@@ -1081,7 +1145,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     uint32_t pendIdx = 0;
     RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
+#if PT_CERT_BOUND16
+    h16x2 kx = rx, ky = rx, kz = rx;             /* per-axis factors of the entry bound's error term (box_pair_bound) */
+#else
     float invx = 0, invy = 0, invz = 0;
+#endif
     uint32_t cur = 0; int sp = 0;
     bool hit = false, tie = false, nearLast = false;
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
@@ -1113,7 +1181,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
         limit0 = r.max_t; otherT = __builtin_huge_valf();
         rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
+#if PT_CERT_BOUND16
+        kx = bound_factor(r.rcpD.x); ky = bound_factor(r.rcpD.y); kz = bound_factor(r.rcpD.z);
+        const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
+#else
         invx = 1.0f / r.d.x; invy = 1.0f / r.d.y; invz = 1.0f / r.d.z;
+#endif
         /* finite and non-zero, all nine: x - x is 0 exactly then, NaN for an infinity or a NaN */
         const float probe = (invx - invx) + (invy - invy) + (invz - invz) + (r.o.x - r.o.x) + (r.o.y - r.o.y) + (r.o.z - r.o.z) +
                             (r.d.x - r.d.x) + (r.d.y - r.d.y) + (r.d.z - r.d.z);
@@ -1185,6 +1258,12 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             bool sL, sR; float tminL, tminR;
             const f32x2 cx = as_f2(q0.x, q0.y), cy = as_f2(q0.z, q0.w), cz = as_f2(q1.x, q1.y);
             const h16x2 ax = as_h2(q1.z), ay = as_h2(q1.w), az = as_h2(q2.x), bx = as_h2(q2.y), by = as_h2(q2.z), bz = as_h2(q2.w);
+#if PT_CERT_BOUND16
+            h16x2 bound16;
+            box_pair_bound(r, rx, ry, rz, kx, ky, kz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR, bound16);
+            bound16 = bound_slack(bound16);
+            float boundL = (float)bound16.x, boundR = (float)bound16.y;
+#else
             box_pair(r, rx, ry, rz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR);
             const f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
             float boundL = 0.0f, boundR = 0.0f;
@@ -1194,6 +1273,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
              * launch (133 against 157 spp/s on certified frames). */
             if (!(MODE == MODE_MIXED && shadowLane))
                 entry_bound(dx, dy, dz, invx, invy, invz, ax, ay, az, bx, by, bz, boundL, boundR);
+#endif
             /* enter unless the order-independent part of the reference's verdict fails or the box certainly begins beyond
                everything that still matters */
             const float reach = fmaxf(r.max_t, hitGate);
@@ -1210,7 +1290,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
             if (pL && pR) {
                 const uint32_t second = rightFirst ? refL : refR;
                 const float boundSecond = rightFirst ? boundL : boundR, tminSecond = rightFirst ? tminL : tminR;
+#if PT_CERT_BOUND16
+                const uint16_t bb = hbits((h16)boundSecond);        /* exact: an fp16 value (the bound, or a shadow ray's tmin), or -inf */
+#else
                 const uint16_t bb = hbits(round_down_h16(boundSecond));
+#endif
                 const uint16_t gb = hbits((h16)fmaxf(pathGate, tminSecond));             /* exact: both came from fp16 values */
                 if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = second; sBound[wave][sp][lane] = bb; sGate[wave][sp][lane] = gb; }
                 else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, (uint32_t)bb | ((uint32_t)gb << 16));
@@ -1309,16 +1393,34 @@ __global__ __launch_bounds__(256) void k_selftest_entry_bound(uint64_t seed, uin
         dd[x] = { cc[0] - o[x], cc[1] - o[x] };
     }
     float boundL, boundR;
+    bool unreachable[2] = { false, false };      /* fp16 tmin of +inf: the reference's max_t > tmin never holds, nothing is claimed */
+#if PT_CERT_BOUND16
+    {
+        RayRegs r; r.o = { o[0], o[1], o[2] }; ray_set_dir(r, { d[0], d[1], d[2] }); r.min_t = 0.0f; r.max_t = __builtin_huge_valf();
+        const h16x2 rx = { r.rcpD.x, r.rcpD.x }, ry = { r.rcpD.y, r.rcpD.y }, rz = { r.rcpD.z, r.rcpD.z };
+        bool sL, sR; float tL, tR; h16x2 b16;
+        box_pair_bound(r, rx, ry, rz, bound_factor(r.rcpD.x), bound_factor(r.rcpD.y), bound_factor(r.rcpD.z), c[0], c[1], c[2],
+                       ha[0], ha[1], ha[2], hb[0], hb[1], hb[2], sL, sR, tL, tR, b16);
+        boundL = (float)b16.x; boundR = (float)b16.y;
+        unreachable[0] = tL == __builtin_huge_valf(); unreachable[1] = tR == __builtin_huge_valf();
+        (void)dd;
+    }
+#else
     entry_bound(dd[0], dd[1], dd[2], 1.0f / d[0], 1.0f / d[1], 1.0f / d[2], ha[0], ha[1], ha[2], hb[0], hb[1], hb[2], boundL, boundR);
+#endif
     for (int k = 0; k < 2; k++) {
         double enter = -1e300, leave = 1e300;
         for (int x = 0; x < 3; x++) {
             const double t0 = ((double)a[k][x] - (double)o[x]) / (double)d[x], t1 = ((double)b[k][x] - (double)o[x]) / (double)d[x];
             enter = fmax(enter, fmin(t0, t1)); leave = fmin(leave, fmax(t0, t1));
         }
-        if (!(enter <= leave)) continue;                                  /* the ray does not reach this box: nothing is claimed */
+        if (!(enter <= leave) || unreachable[k]) continue;                /* the ray does not reach this box: nothing is claimed */
         atomicAdd(out + 0, 1ull);
         const float bound = k == 0 ? boundL : boundR;
+#if PT_CERT_BOUND16
+        if ((double)bound > enter) atomicAdd(out + 1, 1ull);              /* (a NaN bound - every axis overflowed - skips nothing) */
+#else
         if (!((double)bound <= enter)) atomicAdd(out + 1, 1ull);         /* a NaN bound skips nothing, but would hide a mistake: counted too */
+#endif
     }
 }
