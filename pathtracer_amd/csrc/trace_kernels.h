@@ -764,39 +764,36 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
 
 /* ---- treelet walk ---------------------------------------------------------------------------------
  *
- * One step = one PtTreelet (128 B, eight 16 B loads) or one PtTri (64 B): the boxes of both children L, R of the node
- * AND of their children come with one fetch, so a ray pays one dependent fetch per two levels of the tree and every
- * byte of the line is used.  All six box tests run at once (three packed pair tests); what they decide is exactly what
- * the two-box walk decides, node by node, in the same order and with the same max_t:
+ * One step = one PtTreelet (128 B, eight 16 B loads) or one PtTri (64 B).  The record of a node X holds the boxes of
+ * X's children L, R and of their children, so a ray pays one dependent fetch per two levels of the tree where the
+ * walk descends, and every byte of the line it fetched is there to be used.  Node for node the walk is k_trace_flat's:
  *
- *   - L and R are judged now, with the max_t of now, as the two-box walk judges them when it visits the node;
- *   - the half entered first (the nearer one if ORDERED, else L) is entered at once: a leaf goes to its triangle; of an
- *     interior half's children, judged now as well (the two-box walk would visit that half next, with the same max_t),
- *     the first is entered and the second waits on the stack with its tmin, re-checked against max_t when it is popped;
- *   - the other half waits.  The two-box walk would pop it later, check max_t > its tmin with the max_t of THEN, fetch it
- *     and judge its children with that same max_t.  Here its children's boxes are already known, so they wait in its
- *     place: each with its own tmin as gate, the one to be popped first (PT_PAIR_BIT if its sibling lies beneath it)
- *     also with the half's tmin as parent gate.  When it is popped, the parent gate is evaluated with the max_t of that
- *     moment - the moment the two-box walk pops the half; if it fails, the sibling beneath goes with it; if it holds,
- *     the sibling stays with its own gate only (the half was entered, and max_t only shrinks from there on).  The
- *     order among the two children is by tmin (ORDERED) exactly as the two-box walk orders two children that both
- *     pass: if only one of them would pass at that time it is the one with the smaller tmin, which is on top.
+ *   stage A (a lane that arrives at X): L and R are judged with the max_t of now, as the two-box walk judges them when
+ *     it visits X; the half entered first is the nearer one (ORDERED) or L; if both pass, the other half waits on the
+ *     stack as ONE entry with its tmin - a leaf half as its triangle, an interior half as "X's record, this half"
+ *     (PT_HALF_BIT) - and `max_t > tmin` is evaluated again when it is popped, exactly as the two-box walk does with
+ *     the sibling it pushed;
+ *   stage B (the same lane in the same step if the half it enters is interior; or a lane that popped a waiting half):
+ *     the half's two children, whose boxes are in the record already, are judged with the max_t of now - the two-box
+ *     walk would fetch the half's record for this - the first is entered, the second waits with its tmin.
  *
- * So the leaves tested, their order and the max_t each is tested with are those of k_trace_flat<ORDERED>, and hits
- * are bit-identical to it (and, with ORDERED = false, to the reference's walk).  A level of this walk can leave three
- * entries behind where two levels of the two-box walk leave two; the spill area is sized for that. */
+ * A popped interior half fetches X's record a second time (the line is often still in a cache) and runs stage B only.
+ * So the boxes tested, their order and the max_t each test sees are those of k_trace_flat<ORDERED>: hits are bit-identical
+ * to it (and, with ORDERED = false, to the reference's walk), and the stack holds one entry per level, as there. */
+#define PT_HALF_BIT   0x40000000u       /* traversal reference: enter the record at one of its halves (stage B only) */
+#define PT_HALF_RIGHT 0x20000000u       /* ... the right one */
+#define PT_UNIT_MASK  0x03FFFFFFu
 template <int MODE, bool ANYHIT, bool ORDERED, bool COUNT>
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
 {
     __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
-    __shared__ uint32_t sGate[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];     /* own tmin | parent's tmin << 16, fp16 bits */
+    __shared__ uint16_t sTmin[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
     const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
     const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.treelets, 0, (int)a.treeletBytes, 0x00020000);
-    const uint32_t NO_GATE = 0xFC00u;                                   /* -inf: max_t > -inf always holds */
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
     bool active = false, pend = false;
@@ -835,9 +832,11 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
         if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
         else store(false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
     };
-    auto push = [&](uint32_t ref, uint32_t gates) {
-        if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = ref; sGate[wave][sp][lane] = gates; }
-        else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(ref, gates);
+    /* the one push site: the sibling waits with its tmin; `max_t > tmin` is re-evaluated when it is popped */
+    auto push = [&](uint32_t ref, float tmin) {
+        const uint16_t tb = hbits((h16)tmin);                 /* exact: tmin came from an fp16 */
+        if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = ref; sTmin[wave][sp][lane] = tb; }
+        else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(ref, tb);
         sp++;
     };
 
@@ -859,7 +858,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
 
         if (active) {
         const bool leaf = (cur & PT_LEAF_BIT) != 0;
-        const uint32_t unit = cur & 0x03FFFFFFu;
+        const uint32_t unit = cur & PT_UNIT_MASK;
         const uint32_t off = unit * 64u;
         u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
@@ -896,71 +895,62 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
             }
         } else {
             /* words 0..9 pair (L, R), 10..19 pair (LL, LR), 20..29 pair (RL, RR), 30..31 links */
-            const uint32_t d0 = q2.y, d1 = q4.w, d2 = q7.y;
-            bool sL, sR, sLa, sLb, sRa, sRb; float tL, tR, tLa, tLb, tRa, tRb;
-            box_pair(r, rx, ry, rz, as_f2(q0.x, q0.y), as_f2(q0.z, q0.w), as_f2(q1.x, q1.y), as_h2(q1.z), as_h2(q1.w), as_h2(q2.x),
-                     rebuild_b(q1.z, d0, 0), rebuild_b(q1.w, d0, 1), rebuild_b(q2.x, d0, 2), sL, sR, tL, tR);
-            box_pair(r, rx, ry, rz, as_f2(q2.z, q2.w), as_f2(q3.x, q3.y), as_f2(q3.z, q3.w), as_h2(q4.x), as_h2(q4.y), as_h2(q4.z),
-                     rebuild_b(q4.x, d1, 0), rebuild_b(q4.y, d1, 1), rebuild_b(q4.z, d1, 2), sLa, sLb, tLa, tLb);
-            box_pair(r, rx, ry, rz, as_f2(q5.x, q5.y), as_f2(q5.z, q5.w), as_f2(q6.x, q6.y), as_h2(q6.z), as_h2(q6.w), as_h2(q7.x),
-                     rebuild_b(q6.z, d2, 0), rebuild_b(q6.w, d2, 1), rebuild_b(q7.x, d2, 2), sRa, sRb, tRa, tRb);
-            const bool leafL = (d0 & 0x8000u) != 0, leafR = (d0 & 0x80000000u) != 0;
-            if (COUNT) nBox += 2 + (leafL ? 0 : 2) + (leafR ? 0 : 2);
-            /* starts of the four targets */
+            const uint32_t d0 = q2.y;
+            bool goRight = (cur & PT_HALF_RIGHT) != 0;           /* a popped half says which; stage A decides otherwise */
+            bool enterHalf = (cur & PT_HALF_BIT) != 0;
+            /* starts of the four targets: T0 right behind the record, T1..T3 from the link word */
             const uint32_t w0 = q7.z, w1 = q7.w;
             const uint32_t sh = (w1 >> 31) ? 5u : 0u;
             const uint32_t u0 = unit + 2u;
             const uint32_t u1 = unit + ((w0 & 0x1FFFFFu) << sh);
             const uint32_t u2 = unit + ((((w0 >> 21) | (w1 << 11)) & 0x1FFFFFu) << sh);
             const uint32_t u3 = unit + (((w1 >> 10) & 0x1FFFFFu) << sh);
-            /* references as the walk uses them: unit | leaf bit.  A leaf half has one target, its triangle */
-            const uint32_t refLa = u0 | ((leafL || (d1 & 0x8000u)) ? PT_LEAF_BIT : 0u), refLb = u1 | ((d1 & 0x80000000u) ? PT_LEAF_BIT : 0u);
-            const uint32_t refRa = u2 | ((leafR || (d2 & 0x8000u)) ? PT_LEAF_BIT : 0u), refRb = u3 | ((d2 & 0x80000000u) ? PT_LEAF_BIT : 0u);
-
-            const bool pL = sL && r.max_t > tL, pR = sR && r.max_t > tR;
-            const bool rightFirst = (ORDERED && pL && pR && tR < tL) || !pL;
-            /* the half entered first (1) and the half that waits (2) */
-            const bool leaf1 = rightFirst ? leafR : leafL, leaf2 = rightFirst ? leafL : leafR;
-            const uint32_t ref1a = rightFirst ? refRa : refLa, ref1b = rightFirst ? refRb : refLb;
-            const uint32_t ref2a = rightFirst ? refLa : refRa, ref2b = rightFirst ? refLb : refRb;
-            const bool s1a = rightFirst ? sRa : sLa, s1b = rightFirst ? sRb : sLb, s2a = rightFirst ? sLa : sRa, s2b = rightFirst ? sLb : sRb;
-            const float t1a = rightFirst ? tRa : tLa, t1b = rightFirst ? tRb : tLb, t2a = rightFirst ? tLa : tRa, t2b = rightFirst ? tLb : tRb;
-            const float t2 = rightFirst ? tL : tR;
-
-            if (pL && pR) {                                    /* the second half waits: as itself if a leaf, else as its children */
-                const uint32_t g2 = (uint32_t)hbits((h16)t2);                                /* exact: every tmin came from an fp16 */
-                if (leaf2) push(ref2a, g2 | (NO_GATE << 16));
-                else {
-                    const bool bFirst = ORDERED && s2a && s2b && t2b < t2a;
-                    if (s2a && s2b) {
-                        push(bFirst ? ref2a : ref2b, (uint32_t)hbits((h16)(bFirst ? t2a : t2b)) | (NO_GATE << 16));
-                        push((bFirst ? ref2b : ref2a) | PT_PAIR_BIT, (uint32_t)hbits((h16)(bFirst ? t2b : t2a)) | (g2 << 16));
-                    } else if (s2a || s2b) {
-                        push(s2a ? ref2a : ref2b, (uint32_t)hbits((h16)(s2a ? t2a : t2b)) | (g2 << 16));
+            if (!enterHalf) {                                    /* stage A: the two-box walk's visit of X */
+                if (COUNT) nBox += 2;
+                bool sL, sR; float tL, tR;
+                box_pair(r, rx, ry, rz, as_f2(q0.x, q0.y), as_f2(q0.z, q0.w), as_f2(q1.x, q1.y), as_h2(q1.z), as_h2(q1.w), as_h2(q2.x),
+                         rebuild_b(q1.z, d0, 0), rebuild_b(q1.w, d0, 1), rebuild_b(q2.x, d0, 2), sL, sR, tL, tR);
+                const bool pL = sL && r.max_t > tL, pR = sR && r.max_t > tR;
+                if (pL || pR) {
+                    const bool leafL = (d0 & 0x8000u) != 0, leafR = (d0 & 0x80000000u) != 0;
+                    goRight = (ORDERED && pL && pR && tR < tL) || !pL;
+                    if (pL && pR) {                              /* the other half waits */
+                        const bool farLeaf = goRight ? leafL : leafR;
+                        const uint32_t farTri = (goRight ? u0 : u2) | PT_LEAF_BIT;
+                        const uint32_t farHalf = unit | PT_HALF_BIT | (goRight ? 0u : PT_HALF_RIGHT);
+                        push(farLeaf ? farTri : farHalf, goRight ? tL : tR);
                     }
+                    if (goRight ? leafR : leafL) { cur = (goRight ? u2 : u0) | PT_LEAF_BIT; needPop = false; }
+                    else enterHalf = true;
                 }
             }
-            if (pL || pR) {
-                if (leaf1) { cur = ref1a; needPop = false; }
-                else {
-                    const bool pa = s1a && r.max_t > t1a, pb = s1b && r.max_t > t1b;
-                    const bool bFirst = (ORDERED && pa && pb && t1b < t1a) || !pa;
-                    if (pa && pb) push(bFirst ? ref1a : ref1b, (uint32_t)hbits((h16)(bFirst ? t1a : t1b)) | (NO_GATE << 16));
-                    if (pa || pb) { cur = bFirst ? ref1b : ref1a; needPop = false; }
-                }
+            if (enterHalf) {                                     /* stage B: the two-box walk's visit of the half */
+                if (COUNT) nBox += 2;
+                const uint32_t c0 = goRight ? q5.x : q2.z, c1 = goRight ? q5.y : q2.w, c2 = goRight ? q5.z : q3.x;
+                const uint32_t c3 = goRight ? q5.w : q3.y, c4 = goRight ? q6.x : q3.z, c5 = goRight ? q6.y : q3.w;
+                const uint32_t h0 = goRight ? q6.z : q4.x, h1 = goRight ? q6.w : q4.y, h2 = goRight ? q7.x : q4.z;
+                const uint32_t dd = goRight ? q7.y : q4.w;
+                bool sA, sB; float tA, tB;
+                box_pair(r, rx, ry, rz, as_f2(c0, c1), as_f2(c2, c3), as_f2(c4, c5), as_h2(h0), as_h2(h1), as_h2(h2),
+                         rebuild_b(h0, dd, 0), rebuild_b(h1, dd, 1), rebuild_b(h2, dd, 2), sA, sB, tA, tB);
+                const bool pA = sA && r.max_t > tA, pB = sB && r.max_t > tB;
+                const uint32_t refA = (goRight ? u2 : u0) | ((dd & 0x8000u) ? PT_LEAF_BIT : 0u);
+                const uint32_t refB = (goRight ? u3 : u1) | ((dd & 0x80000000u) ? PT_LEAF_BIT : 0u);
+                const bool bFirst = (ORDERED && pA && pB && tB < tA) || !pA;
+                if (pA && pB) push(bFirst ? refA : refB, bFirst ? tA : tB);
+                if (pA || pB) { cur = bFirst ? refB : refA; needPop = false; }
             }
         }
 
+        /* pending siblings come off the stack until one still passes `max_t > tmin` */
         while (needPop) {
             if (sp == 0) { done = true; break; }
             sp--;
             const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
-            uint32_t ref = sRef[wave][e][lane], gates = sGate[wave][e][lane];
+            uint32_t ref = sRef[wave][e][lane]; uint16_t tb = sTmin[wave][e][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; gates = o.y; }
-            const bool parentOk = r.max_t > (float)hi16(gates);
-            if (parentOk && r.max_t > (float)lo16(gates)) { cur = ref & ~PT_PAIR_BIT; needPop = false; }
-            else if (!parentOk && (ref & PT_PAIR_BIT)) sp--;                /* its sibling beneath hangs on the same parent */
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; tb = (uint16_t)o.y; }
+            if (r.max_t > (float)hfrombits(tb)) { cur = ref; needPop = false; }
         }
 
         if (done) {
