@@ -1116,12 +1116,23 @@ __device__ __forceinline__ h16x2 bound_slack(h16x2 b)
 /* MODE_RAYS, MODE_JOBS, or MODE_MIXED: a job list and, behind it, a shadow queue in one pool (see k_trace_flat).  A lane with
  * a shadow ray walks near child first with the reference's own culling and stops at the first hit: nothing about an any-hit
  * verdict depends on the order, so there is nothing to certify. */
+#ifndef PT_CERT_STACK_LDS
+#define PT_CERT_STACK_LDS PT_STACK_LDS
+#endif
+#ifndef PT_CERT_LEAF_MIN
+#define PT_CERT_LEAF_MIN 8       /* batches: lanes at a leaf wait for this many before the triangle tests run (4 / 8 / 12 / 16: 28.8 / 28.4 / 28.4 / 28.7 ms; 1 = never wait: 29.3) */
+#endif
+#ifdef PT_CERT_WAVES
+#define PT_CERT_ATTR __attribute__((amdgpu_waves_per_eu(PT_CERT_WAVES, PT_CERT_WAVES)))
+#else
+#define PT_CERT_ATTR
+#endif
 template <int MODE, bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
+__global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs a)
 {
-    __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
-    __shared__ uint16_t sBound[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];      /* entry bound of the waiting child, rounded down */
-    __shared__ uint16_t sGate[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];       /* largest fp16 tmin from the root down to it */
+    __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][64];
+    __shared__ uint16_t sBound[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][64];      /* entry bound of the waiting child, rounded down */
+    __shared__ uint16_t sGate[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][64];       /* largest fp16 tmin from the root down to it */
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
@@ -1133,7 +1144,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     bool active = false, pend = false;
     bool shadowLane = false, freshShadow = false;      /* MODE_MIXED: what kind of ray the lane walks / has just loaded */
     uint32_t pendIdx = 0;
-    RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
+    RayRegs r; uint32_t exclude = 0, tag = 0;
+    uint32_t id = 0;                      /* a launch has fewer than 2^32 rays: one register, not two */
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
 #if PT_CERT_BOUND16
     h16x2 kx = rx, ky = rx, kz = rx;             /* per-axis factors of the entry bound's error term (box_pair_bound) */
@@ -1145,7 +1157,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
     float alpha = 0, beta = 0, gamma = 0;
     float pathGate = 0, hitGate = 0;      /* largest fp16 tmin on the way to the current record / to the hit held */
-    float limit0 = 0, otherT = 0;         /* the ray's own max_t; smallest t of any other triangle the ray was seen to hit */
+    float limitReg = 0, otherT = 0;       /* the ray's own max_t (batches; a job's is the constant of trace.comp:190); smallest t of any other triangle the ray was seen to hit */
+#define limit0 (MODE == MODE_RAYS ? limitReg : 100000.0f)
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
     const float NEG_INF = -__builtin_huge_valf();
 
@@ -1169,7 +1182,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         else { shadowLane = freshShadow; if (shadowLane) finish_ray<MODE_SHADOW>(w, r, exclude, tag); else finish_ray<MODE_JOBS>(w, r, exclude, tag); }
         if (COUNT) { nRay++; nBox++; }
         hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
-        limit0 = r.max_t; otherT = __builtin_huge_valf();
+        limitReg = r.max_t; otherT = __builtin_huge_valf();
         rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
 #if PT_CERT_BOUND16
         kx = bound_factor(r.rcpD.x); ky = bound_factor(r.rcpD.y); kz = bound_factor(r.rcpD.z);
@@ -1204,16 +1217,27 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         if (nIdle == 64 && pool.exhausted()) break;
         bool fresh = false;
         RayWords w;
-        if (pend) { id = pendIdx; pend = false; fresh = issue(id, w); }
+        if (MODE == MODE_RAYS && pend) { id = pendIdx; pend = false; fresh = issue(id, w); }      /* only batches come with an order */
         if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
             uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
             if (canTake && nid != ~0ull) {
-                if (a.order) { pendIdx = a.order[nid]; pend = true; }
-                else { id = nid; fresh = issue(id, w); }
+                if (MODE == MODE_RAYS && a.order) { pendIdx = a.order[nid]; pend = true; }
+                else { id = (uint32_t)nid; fresh = issue(id, w); }
             }
         }
 
-        if (active) {
+        /* Leaves wait (batches): a lane that stands at a leaf sits steps out until PT_CERT_LEAF_MIN lanes of its wavefront stand
+           at one, or no lane has anything else to do, so that the triangle test and the bookkeeping behind it are issued for
+           several lanes at a time instead of for two or three in nearly every step.  Every lane's own sequence of tests and
+           the max_t each sees are unchanged, hence its result.  (This walk's step is the longest of the traversal kernels;
+           the near-first walks, measured the same way, gain nothing: their launches wait for memory, not for instructions.) */
+        bool stepNow = active;
+        if (MODE == MODE_RAYS && PT_CERT_LEAF_MIN > 1) {
+            const bool atLeaf = active && (cur & PT_LEAF_BIT) != 0;
+            const uint64_t leafMask = __ballot(atLeaf), actMask = __ballot(active);
+            if (__popcll(leafMask) < PT_CERT_LEAF_MIN && leafMask != actMask) stepNow = active && !atLeaf;
+        }
+        if (stepNow) {
         const bool leaf = (cur & PT_LEAF_BIT) != 0;
         const uint32_t off = (cur & ~PT_LEAF_BIT) * 64u + (leaf ? a.leafBase : 0u);
         u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
@@ -1286,8 +1310,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
                 const uint16_t bb = hbits(round_down_h16(boundSecond));
 #endif
                 const uint16_t gb = hbits((h16)fmaxf(pathGate, tminSecond));             /* exact: both came from fp16 values */
-                if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = second; sBound[wave][sp][lane] = bb; sGate[wave][sp][lane] = gb; }
-                else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, (uint32_t)bb | ((uint32_t)gb << 16));
+                if (sp < PT_CERT_STACK_LDS) { sRef[wave][sp][lane] = second; sBound[wave][sp][lane] = bb; sGate[wave][sp][lane] = gb; }
+                else a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid] = make_uint2(second, (uint32_t)bb | ((uint32_t)gb << 16));
                 sp++;
             }
             if (pL || pR) {
@@ -1301,10 +1325,10 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
         while (needPop) {
             if (sp == 0) { done = true; break; }
             sp--;
-            const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
+            const int e = sp < PT_CERT_STACK_LDS ? sp : PT_CERT_STACK_LDS - 1;
             uint32_t ref = sRef[wave][e][lane]; uint16_t bb = sBound[wave][e][lane], gb = sGate[wave][e][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; bb = (uint16_t)o.y; gb = (uint16_t)(o.y >> 16); }
+            if (sp >= PT_CERT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid]; ref = o.x; bb = (uint16_t)o.y; gb = (uint16_t)(o.y >> 16); }
             const float waiting = (float)hfrombits(bb);
             const bool enter = (MODE == MODE_MIXED && shadowLane) ? r.max_t > waiting : !(waiting > fmaxf(r.max_t, hitGate));
             if (enter) { cur = ref; pathGate = (float)hfrombits(gb); needPop = false; }
@@ -1322,6 +1346,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_cert(TraceArgs a)
     if (COUNT) {
         atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
     }
+#undef limit0
 }
 
 /* Self-test of entry_bound, the lemma the certified walk rests on: for random fp32 boxes [a, b] (sizes and offsets over
