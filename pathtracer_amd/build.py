@@ -7,7 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptcore.so")
 SOURCES = ["ptcore.hip", "bvh_build.cpp", "ply.cpp", "scene_prep.cpp", "frame_dump.cpp"]
-HEADERS = ["device_math.h", "trace_kernels.h", "frame_kernels.h", "sort_kernels.h", "../../include/ptcore.h"]
+HEADERS = ["device_math.h", "trace_kernels.h", "frame_kernels.h", "sort_kernels.h", "../../include/ptcore.h",
+           "context_impl.h", "launch_impl.h", "pipeline_impl.h", "train_impl.h", "batch_impl.h", "scene_impl.h", "comm_impl.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference's arithmetic is restated operation by operation; a fused
 # multiply-add would change results.  Division and sqrt stay correctly rounded (hipcc default).

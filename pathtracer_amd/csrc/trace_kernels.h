@@ -29,6 +29,22 @@
 
 #pragma clang fp contract(off)
 
+/* Diagnostic builds of k_trace_flat (extra loads or instructions per step, cycle counters, a refill that waits for its own
+ * loads, same-line statistics) hang on seven hooks that are empty in the product: the code behind them lives in
+ * trace_diagnostics.h, which only a build with -DPT_DIAGNOSTICS includes (scripts/build_variant.sh <name> -DPT_DIAGNOSTICS
+ * -DPT_EXPERIMENT_...). */
+#ifdef PT_DIAGNOSTICS
+#include "trace_diagnostics.h"
+#else
+#define PT_DIAG_STATE
+#define PT_DIAG_COUNT_ROOT_BOX nBox++;
+#define PT_DIAG_AFTER_REFILL
+#define PT_DIAG_BEFORE_FETCH
+#define PT_DIAG_AFTER_FETCH
+#define PT_DIAG_COUNT_BOX_PAIR nBox += 2;
+#define PT_DIAG_AT_EXIT
+#endif
+
 #ifndef PT_STACK_LDS
 #define PT_STACK_LDS 12          /* per-lane stack entries held in LDS; deeper entries spill to global memory */
 #endif
@@ -572,12 +588,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1; uint32_t hitLeaf = 0;     /* ids come with the leaf record: no second fetch when the ray ends */
     float alpha = 0, beta = 0, gamma = 0;
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
-#ifdef PT_EXPERIMENT_SAMELINE
-    uint32_t prevLine = 0xFFFFFFFFu;
-#endif
-#ifdef PT_EXPERIMENT_TIMING
-    unsigned long long tFetch = 0, tIter = 0, nIter = 0, nLaneSteps = 0, t0 = __builtin_amdgcn_s_memtime();
-#endif
+    PT_DIAG_STATE
 
     const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
     const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
@@ -597,11 +608,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     auto start_ray = [&](const RayWords& w) {
         if (MODE != MODE_MIXED) finish_ray<MODE>(w, r, exclude, tag);
         else { shadowLane = freshShadow; if (shadowLane) finish_ray<MODE_SHADOW>(w, r, exclude, tag); else finish_ray<MODE_JOBS>(w, r, exclude, tag); }
-#ifdef PT_EXPERIMENT_SAMELINE
-        if (COUNT) { nRay++; prevLine = 0xFFFFFFFFu; }
-#else
-        if (COUNT) { nRay++; nBox++; }
-#endif
+        if (COUNT) { nRay++; PT_DIAG_COUNT_ROOT_BOX }
         /* origBvhId is a reference node index (a leaf's); 48 B records are told apart by their reference */
         if (COMPACT && exclude != 0) exclude = PT_LEAF_BIT | ((uint32_t)(-a.nodes[exclude].right) / 3u);
         hit = false; ranOff = false; sp = 0;
@@ -633,9 +640,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 else { id = nid; fresh = issue(id, w); }
             }
         }
-#ifdef PT_SYNC_REFILL
-        if (fresh) { start_ray(w); fresh = false; }     /* diagnostic: the refill waits for its own loads */
-#endif
+        PT_DIAG_AFTER_REFILL
 
         if (active) {
         /* ---- one step: fetch the 64 B record `cur` names with four 16 B buffer loads issued back to back (the
@@ -643,9 +648,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 the L2 requests), then run two box tests or one triangle test ---- */
         const bool leaf = (cur & PT_LEAF_BIT) != 0;
         const uint32_t off = (cur & ~PT_LEAF_BIT) * (COMPACT ? (uint32_t)PT_COMPACT_STRIDE : 64u) + (leaf ? a.leafBase : 0u);
-#ifdef PT_EXPERIMENT_TIMING
-        unsigned long long ta = __builtin_amdgcn_s_memtime();
-#endif
+        PT_DIAG_BEFORE_FETCH
         u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
         u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
@@ -656,26 +659,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
             q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
             asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
         }
-#ifdef PT_EXPERIMENT_EXTRA_LOAD
-        { u32x4 q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0); asm volatile("" :: "v"(q4)); }   /* diagnostic: cost of one more 16 B access to the same line */
-#endif
-#ifdef PT_EXPERIMENT_TIMING
-        unsigned long long tb_ = __builtin_amdgcn_s_memtime();
-        { unsigned long long am = __ballot(true); if (lane == __ffsll(am) - 1) { tFetch += tb_ - ta; nIter++; nLaneSteps += __popcll(am); } }
-#endif
+        PT_DIAG_AFTER_FETCH
         if (COUNT) nRec++;
-#ifdef PT_EXPERIMENT_EXTRA_VALU
-        {   /* diagnostic: how much does the step's time depend on its vector instruction count? */
-            float dummy = __uint_as_float(q0.x);
-#pragma unroll
-            for (int k = 0; k < PT_EXPERIMENT_EXTRA_VALU; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
-            asm volatile("" :: "v"(dummy));
-        }
-#endif
-#ifdef PT_EXPERIMENT_SAMELINE
-        /* diagnostic: the box-test counter counts steps whose record lies in the 128 B line of the previous step's */
-        if (COUNT) { if ((off >> 7) == prevLine) nBox++; prevLine = off >> 7; }
-#endif
         bool needPop = true, done = false;
 
         if (leaf) {
@@ -698,9 +683,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 }
             }
         } else {
-#ifndef PT_EXPERIMENT_SAMELINE
-            if (COUNT) nBox += 2;
-#endif
+            if (COUNT) { PT_DIAG_COUNT_BOX_PAIR }
             bool sL, sR; float tminL, tminR;
             uint32_t refL, refR;
             if (COMPACT) {
@@ -750,13 +733,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
         /* ---- the rays loaded above start here; they step with the others from the next turn ---- */
         if (fresh) start_ray(w);
     }
-#ifdef PT_EXPERIMENT_TIMING
-    /* diagnostic build only: per-wave cycle sums go to the stats words, which nothing else reads in this build */
-    tIter = __builtin_amdgcn_s_memtime() - t0;
-    atomicAdd(a.stats + 0, tFetch); atomicAdd(a.stats + 2, nIter); atomicAdd(a.stats + 3, nLaneSteps);
-    if (lane == 0) atomicAdd(a.stats + 1, tIter);
-    return;
-#endif
+    PT_DIAG_AT_EXIT
     if (COUNT) {
         atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
     }
