@@ -501,12 +501,16 @@ def certified_frames(ctx, num_triangles, num_nodes):
         ctx.render_samples(20, nf)
         ctx.synchronize()
         dt = time.perf_counter() - t
+        roof = frame_roofline(ctx, num_triangles, W, H, NR, nf)
     finally:
         ctx.set_option(core.OPT_TRAVERSAL, 2)
     differ = lambda a, b: int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())
-    return {"spp_per_s_1080p": round(nf / dt, 2), "frames_timed": nf,
-            "pixels_differing_from_the_reference_order_walk_after_6_frames": differ(acc[3], acc[1]),
-            "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
+    out = {"spp_per_s_1080p": round(nf / dt, 2), "frames_timed": nf,
+           "pixels_differing_from_the_reference_order_walk_after_6_frames": differ(acc[3], acc[1]),
+           "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
+    if roof:
+        out["roofline"] = roof
+    return out
 
 
 def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=240, camera=None, NR=8, per_call=False):
@@ -525,8 +529,15 @@ def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=240, camer
     dt = time.perf_counter() - t
     rc = ctx.render_sample(100 + nf, want_ray_counts=True)
     rays = int(rc[:2 * NR].sum())
-    out = {f"spp_per_s_{H}p": round(nf / dt, 2), "frames_timed": nf, "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
-           "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1)}
+    spp = nf / dt
+    out = {f"spp_per_s_{H}p": round(spp, 2), "frames_timed": nf, "triangles": int(num_triangles), "bounces": NR, "next_event_estimation": True,
+           "rays_per_sample": rays, "Mrays_per_s": round(rays * nf / dt / 1e6, 1),
+           # rays of one sample by bounce (closest-hit rays traced at that depth, shadow rays its shade pass queued) x samples per second
+           "Mrays_per_s_by_bounce": {"closest_hit": [round(float(rc[2 * d]) * spp / 1e6, 1) for d in range(NR)],
+                                     "shadow": [round(float(rc[2 * d + 1]) * spp / 1e6, 1) for d in range(NR)]}}
+    roof = frame_roofline(ctx, num_triangles, W, H, NR, nf)
+    if roof:
+        out["roofline"] = roof
     if per_call:
         # the reference's own calling pattern (one f_onRender per frame, PathTracer.cpp:672): one render call per frame, with
         # the frame train flushed at the end of every call (library default) and kept between the calls (PT_OPT_TRAIN_KEEP)
@@ -543,6 +554,54 @@ def path_tracer_spp(ctx, num_triangles, num_nodes, W=1920, H=1080, nf=240, camer
             ctx.synchronize()
             out["spp_per_s_one_frame_per_call" + ("_train_kept" if keep else "")] = round((nf // 2) / (time.perf_counter() - t), 2)
         ctx.set_option(core.OPT_TRAIN_KEEP, 0)
+    return out
+
+
+def frame_roofline(ctx, num_triangles, W, H, NR, nf):
+    """The frame train's traversal launch (one per band of rows and step: the closest-hit rays of every frame in flight and the
+    shadow rays of the step before) on the same footing as the batch kernel: its mean duration measured here with HIP event
+    pairs on the launches' own streams (PT_OPT_TIME_TRAVERSAL, a separate short render so that the timed frame rate above carries
+    no events), against the bytes that crossed the fabric per launch, the L2 hit rate and the vector ALU's busy share from
+    rocprofv3 --pmc passes of the same workload (profiles/traffic.json; null without a matching record)."""
+    from pathtracer_amd import core
+    trav, layout = ctx.get_option(core.OPT_TRAVERSAL), ctx.get_option(core.OPT_RECORD_LAYOUT)
+    if NR < 3:
+        return None          # short paths go through the per-frame pipeline: no train launch to speak of
+    parts = ctx.get_option(core.OPT_TRAIN_PARTS)
+    frames = min(nf, 64)
+    ctx.set_option(core.OPT_TIME_TRAVERSAL, 1)
+    try:
+        ctx.traversal_ms()                      # start the record over
+        ctx.render_samples(5000, frames)        # frames + NR steps, `parts` launches each, in launch order
+        ms = ctx.traversal_ms()
+    finally:
+        ctx.set_option(core.OPT_TIME_TRAVERSAL, 0)
+    # steps NR .. frames - 1 carry a frame at every depth: the steady state a long render runs in
+    steady = ms[NR * parts: frames * parts]
+    if len(ms) != (frames + NR) * parts or not len(steady):
+        return None
+    kernel_ms = float(steady.mean())
+    launches = int(len(steady))
+    rec = None
+    try:
+        for r in json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["records"]:
+            k = r["key"]
+            if (k.get("kernel") == "frame_train_traversal" and k["triangles"] == int(num_triangles) and k["width"] == W and k["height"] == H
+                    and k["slots"] == NR and k["traversal"] == trav and k.get("record_layout", 0) == layout):
+                rec = r
+    except (OSError, KeyError, ValueError):
+        pass
+    out = {"bound": "hbm", "kernel": "k_trace_cert<MODE_MIXED> + second walk" if trav == 3 else "k_trace_flat<MODE_MIXED>" if not layout == 2 else "k_trace_tree<MODE_MIXED>",
+           "kernel_ms_per_band_step": round(kernel_ms, 3), "bands": parts, "launches_timed": launches, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "traffic": None, "achieved": None, "frac": None, "l2_hit_rate": None, "valu_busy": None, "floor_ratio": None}
+    if rec:
+        traffic = rec["traffic_bytes_per_launch"]
+        gbs = traffic / (kernel_ms * 1e-3) / 1e9
+        out.update({"traffic": traffic, "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4), "l2_hit_rate": rec.get("l2_hit_rate"),
+                    "valu_busy": rec.get("valu_busy"), "traffic_source": rec.get("source")})
+        if rec.get("additive_floor_ms"):
+            # what the chip's measured L2-miss and L2-hit rates alone would take for this launch's misses and hits
+            out["floor_ratio"] = round(rec["additive_floor_ms"] / kernel_ms, 3)
     return out
 
 

@@ -318,6 +318,10 @@ enum {
                                     the all-reduce, a render call that asks for ray counts), after which every buffer is
                                     what frame-by-frame rendering leaves, byte for byte.  While frames are in flight, work
                                     the caller queues on pt_stream is ordered behind the calls above only */
+    PT_OPT_TIME_TRAVERSAL = 18,  /* measurement: 1 = the frame train brackets every traversal launch (one per band of rows and step,
+                                    with the certified walk's second pass inside the bracket) with a HIP event pair on the launch's
+                                    own stream; pt_traversal_ms reads and resets the sums.  At most 4096 launches per reading; the
+                                    events cost a few microseconds per launch, so timed frame rates are taken with it off */
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames the per-frame pipeline keeps in flight (PT_OPT_FRAME_TRAIN = 0, and what
                                     the frame train does not serve), each on its own ray stack and stream; results do not
                                     depend on it.  With merged passes three frames are three streams and HIP's default of
@@ -457,6 +461,11 @@ PT_API int pt_selftest_entry_bound(PtContext* ctx, uint64_t seed, uint64_t num_c
 /* Time of the last traversal launch in milliseconds, measured with HIP events on the
  * context's stream (closest-hit launch of pt_trace_rays, or the sum over a pt_render_sample). */
 PT_API float pt_last_kernel_ms(PtContext* ctx);
+/* With PT_OPT_TIME_TRAVERSAL set: the durations, in milliseconds, of the frame train's traversal launches since the last
+ * reading, in the order they were queued (step by step, within a step band by band), as many as fit `capacity`; *launches
+ * receives their number, and the record starts over.  Launches of different bands overlap in time.  Finishes the frames in
+ * flight and waits for the device first.  No reference counterpart (the reference has no GPU timing at all). */
+PT_API int pt_traversal_ms(PtContext* ctx, float* per_launch_ms, uint32_t capacity, uint32_t* launches);
 
 /* Multi-GPU (no reference counterpart): sums the accumulation buffers of all ranks in place.
  * unique_id is the 128-byte ncclUniqueId made by pt_comm_unique_id on rank 0 and handed to

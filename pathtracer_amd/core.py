@@ -43,6 +43,7 @@ OPT_SHADOW_STREAM = 12
 OPT_MERGE_PASSES = 13
 OPT_TRAIN_MAX_MB = 16            # most device memory (MiB) the frame train may take; 0 = no limit
 OPT_TRAIN_KEEP = 17              # 1: the frame train is kept between render calls (frames stay in flight; render_flush finishes them)
+OPT_TIME_TRAVERSAL = 18          # 1: the frame train times its traversal launches with HIP events (traversal_ms reads the sums)
 OPT_TRAIN_PARTS = 15             # 1..4: bands of rows the frame train renders side by side
 OPT_FRAME_TRAIN = 14             # pt_render_samples steps its frames together, one traversal launch per step: 0 never, 1 always, 2 = for numRays >= 3 or scenes of more than 8 MiB of records (default)
 OPT_SECOND_WALK = 11            # certified walk's second pass: 0 = a ray per lane, 1 = a ray per wavefront (default)
@@ -130,6 +131,7 @@ def _load():
         "pt_copy_to_host": (i32, [vp, vp, vp, sz]),
         "pt_copy_to_device": (i32, [vp, vp, vp, sz]),
         "pt_last_kernel_ms": (C.c_float, [vp]),
+        "pt_traversal_ms": (i32, [vp, vp, u32, C.POINTER(C.c_uint32)]),
         "pt_comm_unique_id": (i32, [vp]),
         "pt_comm_init": (i32, [vp, i32, i32, vp]),
         "pt_allreduce_accumulation": (i32, [vp]),
@@ -471,6 +473,14 @@ class PathTracer:
         a, b = C.c_uint64(0), C.c_uint64(0)
         self._chk(self._L.pt_selftest_entry_bound(self._h, seed, num_cases, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def traversal_ms(self):
+        """Durations (ms, float32 array, launch order) of the frame train's traversal launches since the last reading
+        (OPT_TIME_TRAVERSAL = 1); the record starts over."""
+        out = np.zeros(4096, dtype=np.float32)
+        n = C.c_uint32(0)
+        self._chk(self._L.pt_traversal_ms(self._h, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n)))
+        return out[:min(int(n.value), out.size)].copy()
 
     def last_kernel_ms(self):
         return float(self._L.pt_last_kernel_ms(self._h))

@@ -240,6 +240,19 @@ PT_API int pt_selftest_entry_bound(PtContext* ctx, uint64_t seed, uint64_t num_c
     return 0;
 }
 
+PT_API int pt_traversal_ms(PtContext* ctx, float* per_launch_ms, uint32_t capacity, uint32_t* launches)
+{
+    if (!ctx || !launches || (capacity && !per_launch_ms)) return -1;
+    if (int rc = enter(ctx)) return rc;
+    if (int rc = settle(ctx)) return rc;
+    if (int rc = sync_all(ctx)) return rc;
+    for (size_t i = 0; i < ctx->travUsed && i < capacity; i++)
+        HIPCHK(hipEventElapsedTime(&per_launch_ms[i], ctx->travEvents[i].first, ctx->travEvents[i].second));
+    *launches = (uint32_t)ctx->travUsed;
+    ctx->travUsed = 0;
+    return 0;
+}
+
 PT_API float pt_last_kernel_ms(PtContext* ctx)
 {
     if (!ctx) return -1.0f;

@@ -49,6 +49,7 @@ PT_API void pt_ctx_destroy(PtContext* ctx)
     dfree(ctx->dFetch); dfree(ctx->dStats);
     dfree(ctx->dSortOrder); dfree(ctx->dSortKeys); dfree(ctx->dSortBins);
     dfree(ctx->dFlagList); dfree(ctx->dFlagCtr);
+    for (auto& e : ctx->travEvents) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
@@ -86,6 +87,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_MERGE_PASSES: ctx->optMergePasses = value != 0; return 0;
         case PT_OPT_FRAME_TRAIN: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_FRAME_TRAIN must be 0, 1 or 2"); ctx->optFrameTrain = value; return 0;
         case PT_OPT_TRAIN_KEEP: ctx->optTrainKeep = value != 0; return 0;
+        case PT_OPT_TIME_TRAVERSAL: ctx->optTimeTraversal = value != 0; ctx->travUsed = 0; return 0;
         case PT_OPT_TRAIN_MAX_MB: if (value < 0) return ctx->fail(-1, "PT_OPT_TRAIN_MAX_MB must not be negative"); ctx->optTrainMaxMB = value; return 0;
         case PT_OPT_TRAIN_PARTS: if (value < 1 || value > PT_MAX_TRAIN_PARTS) return ctx->fail(-1, "PT_OPT_TRAIN_PARTS must be 1..4"); ctx->optTrainParts = value; return 0;
         case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
@@ -110,6 +112,7 @@ PT_API int pt_get_option(PtContext* ctx, int option, int* value)
         case PT_OPT_FRAME_TRAIN: *value = ctx->optFrameTrain; return 0;
         case PT_OPT_TRAIN_MAX_MB: *value = ctx->optTrainMaxMB; return 0;
         case PT_OPT_TRAIN_KEEP: *value = ctx->optTrainKeep; return 0;
+        case PT_OPT_TIME_TRAVERSAL: *value = ctx->optTimeTraversal; return 0;
         case PT_OPT_TRAIN_PARTS: *value = ctx->optTrainParts; return 0;
         case PT_OPT_SORT_RAYS: *value = ctx->optSortRays; return 0;
         case PT_OPT_SORT_BITS: *value = ctx->optSortBits; return 0;

@@ -177,9 +177,22 @@ static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
             a.stack = t.dRing; a.hitRecs = p.dHitRecs;
             a.jobs = p.dJobs[cur]; a.countPtr = p.dCtr + TC_NJOBS; a.fetchCounter = p.dCtr + TC_FETCH;
             a.shadowRays = p.dShadow[q]; a.countPtr2 = p.dCtr + TC_NSHADOW + q;
+            /* measurement only (PT_OPT_TIME_TRAVERSAL): an event pair around the launch, at most 4096 per reading */
+            std::pair<hipEvent_t, hipEvent_t>* timed = nullptr;
+            if (ctx->optTimeTraversal && ctx->travUsed < 4096) {
+                if (ctx->travUsed == ctx->travEvents.size()) {
+                    std::pair<hipEvent_t, hipEvent_t> e{ nullptr, nullptr };
+                    HIPCHK(hipEventCreate(&e.first));
+                    if (hipEventCreate(&e.second) != hipSuccess) { (void)hipEventDestroy(e.first); return ctx->fail(-10, "hipEventCreate (traversal timing)"); }
+                    ctx->travEvents.push_back(e);
+                }
+                timed = &ctx->travEvents[ctx->travUsed++];
+                HIPCHK(hipEventRecord(timed->first, p.stream));
+            }
             if (certified) {
                 if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG)) return rc;
             } else if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
+            if (timed) HIPCHK(hipEventRecord(timed->second, p.stream));
         }
         /* parts that start from rest start one after the other, so that their traversal launches do not all thin out at the same time */
         if (t.stagger && k + 1 < t.parts) {

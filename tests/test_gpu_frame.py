@@ -941,3 +941,33 @@ def test_frame_train_random_configurations(bunny, monkey):
             for k, what in enumerate(("accumulation", "current image", "ray counts")):
                 assert np.array_equal(np.asarray(a[k]).view(np.uint8), np.asarray(b[k]).view(np.uint8)), f"{desc}: {what} differs ({how})"
             assert np.array_equal(a[3][live].view(np.uint8), b[3][live].view(np.uint8)), f"{desc}: ray stack differs in a live slot ({how})"
+
+
+@pytest.mark.parametrize("trav,parts", [(core.TRAVERSAL_FLAT_ORDERED, 2), (core.TRAVERSAL_CERTIFIED, 3)])
+def test_traversal_timing_option_counts_launches_and_changes_nothing(gpu_ctx, monkey, trav, parts):
+    """PT_OPT_TIME_TRAVERSAL brackets every traversal launch of the frame train with an event pair: a call of N frames has
+    (N + numRays) steps of `parts` launches each, every one with a positive duration, the record starts over with each
+    reading, nothing is recorded with the option off, and the images are the same bytes either way."""
+    W, H, NR, N = 192, 120, 4, 5
+    _setup(gpu_ctx, monkey, W, H, NR)
+    try:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, trav)
+        gpu_ctx.set_option(core.OPT_TRAIN_PARTS, parts)
+        gpu_ctx.set_option(core.OPT_RESEED, 1)            # a frame then depends on its index only: the two renders below are comparable
+        gpu_ctx.set_constants(_consts(monkey, W, H, NR, 1, {}))
+        gpu_ctx.render_samples(1, N)
+        plain = gpu_ctx.readback_accumulation()
+        assert len(gpu_ctx.traversal_ms()) == 0
+        gpu_ctx.clear_accumulation()
+        gpu_ctx.set_option(core.OPT_TIME_TRAVERSAL, 1)
+        gpu_ctx.render_samples(1, N)
+        ms = gpu_ctx.traversal_ms()
+        assert len(ms) == (N + NR) * parts and (ms > 0).all() and ms.max() < 1000.0
+        assert len(gpu_ctx.traversal_ms()) == 0
+        timed = gpu_ctx.readback_accumulation()
+        assert (timed[..., 3] == N).all() and np.array_equal(plain.view(np.uint8), timed.view(np.uint8))
+    finally:
+        gpu_ctx.set_option(core.OPT_TIME_TRAVERSAL, 0)
+        gpu_ctx.set_option(core.OPT_RESEED, 0)
+        gpu_ctx.set_option(core.OPT_TRAIN_PARTS, 2)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
