@@ -133,7 +133,10 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
     if (ctx->optSecondWalk == 0)
         return launch_trace<MODE, false>(ctx, b, count, stream, area, fixed);    /* traversal 3 maps to the reference-order walk there */
     /* the listed rays are few and their walks long: one wavefront per ray (k_trace_ref_wave); no stack, no spill area */
-    dim3 grid2(ctx->numCUs * 8), block2(64);        /* one wavefront per workgroup */
+#ifndef PT_WAVE_WALK_BLOCKS
+#define PT_WAVE_WALK_BLOCKS 32        /* a batch lists some ten thousand rays: one per wavefront where the chip holds that many (8 / 16 / 32 per CU: 29.31 / 29.09 / 29.00 ms per 2^26-ray call) */
+#endif
+    dim3 grid2(ctx->numCUs * (MODE == MODE_RAYS ? PT_WAVE_WALK_BLOCKS : 8)), block2(64);        /* one wavefront per workgroup */
     if (count) hipLaunchKernelGGL((k_trace_ref_wave<MODE, true>), grid2, block2, 0, stream, b);
     else hipLaunchKernelGGL((k_trace_ref_wave<MODE, false>), grid2, block2, 0, stream, b);
     HIPCHK(hipGetLastError());
