@@ -50,12 +50,15 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
         if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_ref<MODE_RAYS, ANYHIT, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_ref<MODE, ANYHIT, false>), grid, block, 0, stream, a);
     } else if (ctx->dTreelets) {
+        /* batches: the lean step (k_trace_tree); the frame passes: six boxes per step (k_trace_tree6) - each where it measures best */
         if (trav == 1) {
             if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_tree<MODE_RAYS, ANYHIT, false, true>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((k_trace_tree<MODE, ANYHIT, false, false>), grid, block, 0, stream, a);
+            else if (MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_tree<MODE_RAYS, ANYHIT, false, false>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_tree6<MODE, ANYHIT, false, false>), grid, block, 0, stream, a);
         } else {
             if (count && MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_tree<MODE_RAYS, ANYHIT, true, true>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((k_trace_tree<MODE, ANYHIT, true, false>), grid, block, 0, stream, a);
+            else if (MODE == MODE_RAYS) hipLaunchKernelGGL((k_trace_tree<MODE_RAYS, ANYHIT, true, false>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_trace_tree6<MODE, ANYHIT, true, false>), grid, block, 0, stream, a);
         }
     } else if (ctx->compact) {
         if (trav == 1) {
@@ -92,8 +95,8 @@ int launch_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, boo
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
     const bool ordered = ctx->optTraversal == 2;      /* 3 comes here where the certified walk is not to be had: reference order */
     if (ctx->dTreelets) {
-        if (ordered) hipLaunchKernelGGL((k_trace_tree<MODE_MIXED, false, true, false>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((k_trace_tree<MODE_MIXED, false, false, false>), grid, block, 0, stream, a);
+        if (ordered) hipLaunchKernelGGL((k_trace_tree6<MODE_MIXED, false, true, false>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((k_trace_tree6<MODE_MIXED, false, false, false>), grid, block, 0, stream, a);
     } else if (ctx->compact) {
         if (ordered) hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, true, false, true>), grid, block, 0, stream, a);
         else hipLaunchKernelGGL((k_trace_flat<MODE_MIXED, false, false, false, true>), grid, block, 0, stream, a);

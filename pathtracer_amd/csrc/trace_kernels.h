@@ -945,6 +945,222 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
     }
 }
 
+/* ---- treelet walk, six boxes per step (the frame passes) -------------------------------------------
+ *
+ * The same records walked with all six box tests at once (three packed pair tests per step) and nothing fetched twice:
+ *
+ *   - L and R are judged now, with the max_t of now, as the two-box walk judges them when it visits the node;
+ *   - the half entered first (the nearer one if ORDERED, else L) is entered at once: a leaf goes to its triangle; of an
+ *     interior half's children, judged now as well (the two-box walk would visit that half next, with the same max_t),
+ *     the first is entered and the second waits on the stack with its tmin, re-checked against max_t when it is popped;
+ *   - the other half waits.  The two-box walk would pop it later, check max_t > its tmin with the max_t of THEN, fetch it
+ *     and judge its children with that same max_t.  Here its children's boxes are already known, so they wait in its
+ *     place: each with its own tmin as gate, the one to be popped first (PT_PAIR_BIT if its sibling lies beneath it)
+ *     also with the half's tmin as parent gate.  When it is popped, the parent gate is evaluated with the max_t of that
+ *     moment - the moment the two-box walk pops the half; if it fails, the sibling beneath goes with it; if it holds,
+ *     the sibling stays with its own gate only (the half was entered, and max_t only shrinks from there on).  The
+ *     order among the two children is by tmin (ORDERED) exactly as the two-box walk orders two children that both
+ *     pass: if only one of them would pass at that time it is the one with the smaller tmin, which is on top.
+ *
+ * Leaves tested, their order and the max_t each is tested with are again those of k_trace_flat<ORDERED>: identical bits.
+ * A level of this walk can leave three entries behind where two levels of the two-box walk leave two; the spill area is
+ * sized for that.  Which of the two treelet walks runs where is a matter of measurement (5.8 M triangles): a 2^26-ray batch
+ * takes 28.0 ms with this step and 26.8 with k_trace_tree's (the third pair test and the three push sites are most of its
+ * 474 vector instructions, against 294); 1080p x 8 frames run at 186 spp/s with this one and 176 with k_trace_tree's, whose
+ * second fetch of a record is one more dependent round trip in launches that wait for their longest rays. */
+template <int MODE, bool ANYHIT, bool ORDERED, bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void k_trace_tree6(TraceArgs a)
+{
+    __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];
+    __shared__ uint32_t sGate[PT_WAVES_PER_BLOCK][PT_STACK_LDS][64];     /* own tmin | parent's tmin << 16, fp16 bits */
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
+    const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
+    const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
+    const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.treelets, 0, (int)a.treeletBytes, 0x00020000);
+    const uint32_t NO_GATE = 0xFC00u;                                   /* -inf: max_t > -inf always holds */
+
+    RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
+    bool active = false, pend = false;
+    bool shadowLane = MODE == MODE_SHADOW, freshShadow = false;      /* MODE_MIXED: what kind of ray the lane walks / has just loaded */
+    uint32_t pendIdx = 0;
+    RayRegs r; uint32_t exclude = 0, tag = 0; uint64_t id = 0;
+    h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
+    uint32_t cur = 0; int sp = 0;
+    bool hit = false, ranOff = false;
+    int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1; uint32_t hitLeaf = 0;
+    float alpha = 0, beta = 0, gamma = 0;
+    unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
+
+    const h16 rAx = hfrombits(a.rootH[0]), rAy = hfrombits(a.rootH[1]), rAz = hfrombits(a.rootH[2]);
+    const h16 rBx = hfrombits(a.rootH[3]), rBy = hfrombits(a.rootH[4]), rBz = hfrombits(a.rootH[5]);
+
+    /* the three places where a mixed launch has to ask what kind of ray a lane holds (as in k_trace_flat) */
+    auto issue = [&](uint64_t rid, RayWords& w) -> bool {
+        if (MODE != MODE_MIXED) return issue_ray<MODE>(a, rid, w);
+        freshShadow = rid >= numJobs;
+        return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
+    };
+    auto store = [&](bool h, float t, int32_t s1, int32_t s2, int32_t s3, float al, float be, float ga, uint32_t orig) {
+        if (MODE != MODE_MIXED) store_result<MODE>(a, id, tag, h, t, s1, s2, s3, al, be, ga, orig);
+        else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, t, s1, s2, s3, al, be, ga, orig);
+        else store_result<MODE_JOBS>(a, id, tag, h, t, s1, s2, s3, al, be, ga, orig);
+    };
+    auto start_ray = [&](const RayWords& w) {
+        if (MODE != MODE_MIXED) finish_ray<MODE>(w, r, exclude, tag);
+        else { shadowLane = freshShadow; if (shadowLane) finish_ray<MODE_SHADOW>(w, r, exclude, tag); else finish_ray<MODE_JOBS>(w, r, exclude, tag); }
+        if (COUNT) { nRay++; nBox++; }
+        hit = false; ranOff = false; sp = 0;
+        rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
+        float ftmin;
+        bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
+        if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }
+        else store(false, r.max_t, -1, -1, -1, 0, 0, 0, 0);
+    };
+    auto push = [&](uint32_t ref, uint32_t gates) {
+        if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = ref; sGate[wave][sp][lane] = gates; }
+        else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(ref, gates);
+        sp++;
+    };
+
+    for (;;) {
+        const bool canTake = !active && !pend;
+        uint64_t idleMask = __ballot(canTake);
+        int nIdle = __popcll(idleMask);
+        if (nIdle == 64 && pool.exhausted()) break;
+        bool fresh = false;
+        RayWords w;
+        if (MODE != MODE_SHADOW && pend) { id = pendIdx; pend = false; fresh = issue(id, w); }
+        if (!pool.exhausted() && (nIdle >= (int)a.refillMin || nIdle == 64)) {
+            uint64_t nid = pool.claim(a.fetchCounter, canTake, idleMask, nIdle);
+            if (canTake && nid != ~0ull) {
+                if (MODE != MODE_SHADOW && a.order) { pendIdx = a.order[nid]; pend = true; }
+                else { id = nid; fresh = issue(id, w); }
+            }
+        }
+
+        if (active) {
+        const bool leaf = (cur & PT_LEAF_BIT) != 0;
+        const uint32_t unit = cur & 0x03FFFFFFu;
+        const uint32_t off = unit * 64u;
+        u32x4 q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        u32x4 q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16, 0, 0);
+        u32x4 q2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32, 0, 0);
+        u32x4 q3 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 48, 0, 0);
+        u32x4 q4 = { 0u, 0u, 0u, 0u }, q5 = q4, q6 = q4, q7 = q4;
+        if (!leaf) {
+            q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 64, 0, 0);
+            q5 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 80, 0, 0);
+            q6 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 96, 0, 0);
+            q7 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 112, 0, 0);
+        }
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+        asm volatile("" : "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7));
+        if (COUNT) nRec += leaf ? 1 : 2;
+        bool needPop = true, done = false;
+
+        if (leaf) {
+            if ((q3.y & 1u) != 0) ranOff = true;                             /* the reference array's last node was entered */
+            const uint32_t leafId = q3.x;
+            if (exclude == 0 || exclude != leafId) {                         /* intersections.glsl:81 */
+                if (COUNT) nTri++;
+                float t, al, be, ga;
+                F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
+                F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
+                F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
+                if (tri_test(r, p1, e1, e2, t, al, be, ga)) {
+                    r.max_t = t; alpha = al; beta = be; gamma = ga;
+                    hit = true;
+                    if (MODE != MODE_SHADOW) { hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w; }
+                    if (MODE == MODE_JOBS || MODE == MODE_MIXED) hitLeaf = leafId;
+                    if (ANYHIT || (MODE == MODE_MIXED && shadowLane)) { done = true; needPop = false; }
+                }
+            }
+        } else {
+            /* words 0..9 pair (L, R), 10..19 pair (LL, LR), 20..29 pair (RL, RR), 30..31 links */
+            const uint32_t d0 = q2.y, d1 = q4.w, d2 = q7.y;
+            bool sL, sR, sLa, sLb, sRa, sRb; float tL, tR, tLa, tLb, tRa, tRb;
+            box_pair(r, rx, ry, rz, as_f2(q0.x, q0.y), as_f2(q0.z, q0.w), as_f2(q1.x, q1.y), as_h2(q1.z), as_h2(q1.w), as_h2(q2.x),
+                     rebuild_b(q1.z, d0, 0), rebuild_b(q1.w, d0, 1), rebuild_b(q2.x, d0, 2), sL, sR, tL, tR);
+            box_pair(r, rx, ry, rz, as_f2(q2.z, q2.w), as_f2(q3.x, q3.y), as_f2(q3.z, q3.w), as_h2(q4.x), as_h2(q4.y), as_h2(q4.z),
+                     rebuild_b(q4.x, d1, 0), rebuild_b(q4.y, d1, 1), rebuild_b(q4.z, d1, 2), sLa, sLb, tLa, tLb);
+            box_pair(r, rx, ry, rz, as_f2(q5.x, q5.y), as_f2(q5.z, q5.w), as_f2(q6.x, q6.y), as_h2(q6.z), as_h2(q6.w), as_h2(q7.x),
+                     rebuild_b(q6.z, d2, 0), rebuild_b(q6.w, d2, 1), rebuild_b(q7.x, d2, 2), sRa, sRb, tRa, tRb);
+            const bool leafL = (d0 & 0x8000u) != 0, leafR = (d0 & 0x80000000u) != 0;
+            if (COUNT) nBox += 2 + (leafL ? 0 : 2) + (leafR ? 0 : 2);
+            /* starts of the four targets */
+            const uint32_t w0 = q7.z, w1 = q7.w;
+            const uint32_t sh = (w1 >> 31) ? 5u : 0u;
+            const uint32_t u0 = unit + 2u;
+            const uint32_t u1 = unit + ((w0 & 0x1FFFFFu) << sh);
+            const uint32_t u2 = unit + ((((w0 >> 21) | (w1 << 11)) & 0x1FFFFFu) << sh);
+            const uint32_t u3 = unit + (((w1 >> 10) & 0x1FFFFFu) << sh);
+            /* references as the walk uses them: unit | leaf bit.  A leaf half has one target, its triangle */
+            const uint32_t refLa = u0 | ((leafL || (d1 & 0x8000u)) ? PT_LEAF_BIT : 0u), refLb = u1 | ((d1 & 0x80000000u) ? PT_LEAF_BIT : 0u);
+            const uint32_t refRa = u2 | ((leafR || (d2 & 0x8000u)) ? PT_LEAF_BIT : 0u), refRb = u3 | ((d2 & 0x80000000u) ? PT_LEAF_BIT : 0u);
+
+            const bool pL = sL && r.max_t > tL, pR = sR && r.max_t > tR;
+            const bool rightFirst = (ORDERED && pL && pR && tR < tL) || !pL;
+            /* the half entered first (1) and the half that waits (2) */
+            const bool leaf1 = rightFirst ? leafR : leafL, leaf2 = rightFirst ? leafL : leafR;
+            const uint32_t ref1a = rightFirst ? refRa : refLa, ref1b = rightFirst ? refRb : refLb;
+            const uint32_t ref2a = rightFirst ? refLa : refRa, ref2b = rightFirst ? refLb : refRb;
+            const bool s1a = rightFirst ? sRa : sLa, s1b = rightFirst ? sRb : sLb, s2a = rightFirst ? sLa : sRa, s2b = rightFirst ? sLb : sRb;
+            const float t1a = rightFirst ? tRa : tLa, t1b = rightFirst ? tRb : tLb, t2a = rightFirst ? tLa : tRa, t2b = rightFirst ? tLb : tRb;
+            const float t2 = rightFirst ? tL : tR;
+
+            if (pL && pR) {                                    /* the second half waits: as itself if a leaf, else as its children */
+                const uint32_t g2 = (uint32_t)hbits((h16)t2);                                /* exact: every tmin came from an fp16 */
+                if (leaf2) push(ref2a, g2 | (NO_GATE << 16));
+                else {
+                    const bool bFirst = ORDERED && s2a && s2b && t2b < t2a;
+                    if (s2a && s2b) {
+                        push(bFirst ? ref2a : ref2b, (uint32_t)hbits((h16)(bFirst ? t2a : t2b)) | (NO_GATE << 16));
+                        push((bFirst ? ref2b : ref2a) | PT_PAIR_BIT, (uint32_t)hbits((h16)(bFirst ? t2b : t2a)) | (g2 << 16));
+                    } else if (s2a || s2b) {
+                        push(s2a ? ref2a : ref2b, (uint32_t)hbits((h16)(s2a ? t2a : t2b)) | (g2 << 16));
+                    }
+                }
+            }
+            if (pL || pR) {
+                if (leaf1) { cur = ref1a; needPop = false; }
+                else {
+                    const bool pa = s1a && r.max_t > t1a, pb = s1b && r.max_t > t1b;
+                    const bool bFirst = (ORDERED && pa && pb && t1b < t1a) || !pa;
+                    if (pa && pb) push(bFirst ? ref1a : ref1b, (uint32_t)hbits((h16)(bFirst ? t1a : t1b)) | (NO_GATE << 16));
+                    if (pa || pb) { cur = bFirst ? ref1b : ref1a; needPop = false; }
+                }
+            }
+        }
+
+        while (needPop) {
+            if (sp == 0) { done = true; break; }
+            sp--;
+            const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
+            uint32_t ref = sRef[wave][e][lane], gates = sGate[wave][e][lane];
+            asm volatile("" : "+v"(ref));
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; gates = o.y; }
+            const bool parentOk = r.max_t > (float)hi16(gates);
+            if (parentOk && r.max_t > (float)lo16(gates)) { cur = ref & ~PT_PAIR_BIT; needPop = false; }
+            else if (!parentOk && (ref & PT_PAIR_BIT)) sp--;                /* its sibling beneath hangs on the same parent */
+        }
+
+        if (done) {
+            uint32_t orig = 0u;
+            if ((MODE == MODE_JOBS || (MODE == MODE_MIXED && !shadowLane)) && ranOff && hit) orig = hitLeaf;
+            store(hit, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
+            active = false;
+        }
+        }   /* if (active) */
+
+        if (fresh) start_ray(w);
+    }
+    if (COUNT) {
+        atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
+    }
+}
+
 /* ---- certified walk: the reference's answer without the reference's visit order ----------------
  *
  * The reference's closest hit depends on its visit order only because its fp16 box test is not conservative: a
