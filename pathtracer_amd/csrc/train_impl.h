@@ -207,10 +207,9 @@ static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
             f.stack = t.dRing;
             f.jobs = p.dJobs[cur]; f.jobsOut = p.dJobs[cur ^ 1];
             f.shadowRays = p.dShadow[q ^ 1]; f.shadowCtr = p.dCtr + TC_NSHADOW + (q ^ 1);
+            /* a workgroup for every entry the list can have; those beyond its end (known on the device only) leave at once */
             const uint64_t most = (uint64_t)shaded * ppx;
-            uint64_t blocks = (most + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
-            const uint64_t wide = (uint64_t)ctx->numCUs * 32;
-            if (blocks > wide) blocks = wide;
+            const uint64_t blocks = (most + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
             hipLaunchKernelGGL(k_shade_train, dim3((uint32_t)blocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f);
         }
         f.shadowQueue = (uint32_t)q;
