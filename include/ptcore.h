@@ -107,10 +107,12 @@ typedef struct PtNode2 {
                                     packed instruction then works on both children's boxes */
     uint32_t left, right;
     uint32_t refIndex;           /* index of this interior node in the reference array */
-    uint32_t flags;              /* bit 0 / bit 1: the left / right child's subtree holds a triangle so thin (sine of the
-                                    angle between its edges e1, e2 below 2^-14) that the t its triangle test computes
-                                    need not lie anywhere near the triangle; the certified walk never skips such a
-                                    subtree on distance */
+    uint16_t wmax[2];            /* (left child, right child), fp16: an upper bound of the largest magnitude among the
+                                    box's six digested half extents plus 2^-12, which the certified walk's entry bound
+                                    takes for every axis; +inf where the child's subtree holds a triangle so thin (sine
+                                    of the angle between its edges e1, e2 below 2^-14) that the t its triangle test
+                                    computes need not lie anywhere near the triangle: the bound is then -inf and the
+                                    certified walk never skips such a subtree on distance */
 } PtNode2;
 
 /* The same two boxes in 48 B (PT_OPT_RECORD_LAYOUT = 1), three 16 B accesses per lane instead of four.

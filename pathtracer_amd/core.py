@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 NODE_DT = np.dtype([("a", "<f4", 3), ("next", "<i4"), ("b", "<f4", 3), ("right", "<i4")])
 NODE2_DT = np.dtype([("c", "<f4", (3, 2)), ("h", "<u2", (6, 2)), ("left", "<u4"), ("right", "<u4"),
-                     ("refIndex", "<u4"), ("flags", "<u4")])
+                     ("refIndex", "<u4"), ("wmax", "<u2", 2)])
 TRI_DT = np.dtype([("p1", "<f4", 3), ("i1", "<i4"), ("e1", "<f4", 3), ("i2", "<i4"), ("e2", "<f4", 3), ("i3", "<i4"),
                    ("refLeaf", "<u4"), ("flags", "<u4"), ("_pad", "<u4", 2)])
 RAY_DT = np.dtype([("o", "<f4", 3), ("min_t", "<f4"), ("d", "<f4", 3), ("max_t", "<f4")])

@@ -32,6 +32,24 @@ inline void digest_box(const PtBVHNode& n, float c[3], uint16_t h[6])
     }
 }
 
+/* The certified walk's per-box constant: the largest magnitude among the six digested half extents plus 2^-12, rounded up
+ * to fp16 (+inf where that leaves the fp16 range, or where a half extent is not finite). */
+inline uint16_t half_extent_bound(const uint16_t h[6])
+{
+    double w = 0.0;
+    for (int k = 0; k < 6; k++) {
+        const uint16_t m = (uint16_t)(h[k] & 0x7FFFu);
+        _Float16 v; memcpy(&v, &m, 2);
+        if (m >= 0x7C00u) return 0x7C00u;
+        if ((double)v > w) w = (double)v;
+    }
+    w += 0x1p-12;
+    _Float16 r = (_Float16)w;
+    uint16_t u; memcpy(&u, &r, 2);
+    if ((double)r < w) u++;          /* positive and finite: the next bit pattern is the next value up (or +inf) */
+    return u;
+}
+
 void set_err(char* err, size_t n, const char* msg) { if (err && n) snprintf(err, n, "%s", msg); }
 
 /* Is the array the pre-order tree BuildBVH lays down (BVH.cpp:124, 284-304)?  Node i's subtree occupies [i, end): a leaf
@@ -126,6 +144,7 @@ try {
             o.left = child_ref(i + 1);
             o.right = child_ref((uint32_t)n.right);
             o.refIndex = i;
+            o.wmax[0] = half_extent_bound(hl); o.wmax[1] = half_extent_bound(hr);
         } else {
             uint32_t t = rank[i];
             PtTri& o = tris[t];
@@ -157,7 +176,10 @@ try {
             }
         }
         for (uint32_t i = 0; i < num_nodes; i++)
-            if (nodes[i].right > 0) nodes2[rank[i]].flags = (uint32_t)thin[i + 1] | ((uint32_t)thin[nodes[i].right] << 1);
+            if (nodes[i].right > 0) {
+                if (thin[i + 1]) nodes2[rank[i]].wmax[0] = 0x7C00u;
+                if (thin[nodes[i].right]) nodes2[rank[i]].wmax[1] = 0x7C00u;
+            }
     }
 
     if (max_stack) *max_stack = tree_depth(nodes);

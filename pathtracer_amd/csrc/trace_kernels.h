@@ -1171,8 +1171,8 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree6(TraceArgs a)
  *  1. it skips a subtree only when that is safe in every order: the box's fp16 verdict minus its max_t part (which
  *     does not depend on order: a subtree the reference can never enter is not entered here either) must pass, and
  *     the subtree is skipped on distance only if a lower bound of the distance at which the ray enters the box the
- *     builder made (entry_bound: the digested box widened by every rounding between the builder's fp32 box and here,
- *     slab test in fp32, less PT_CERT_SLACK of itself) lies beyond max_t.  Every triangle of a subtree lies inside its
+ *     builder made (box_pair_bound: the box test's own near-plane distances less everything that separates them from
+ *     the exact ones, less PT_CERT_SLACK of itself) lies beyond max_t.  Every triangle of a subtree lies inside its
  *     box, so nothing skipped this way can be nearer than what the walk already holds - as long as the t the triangle
  *     test computes is where the triangle is, to within that slack.  That is the one assumption.  It holds unless the
  *     test's determinant d.(e1 x e2) is lost to rounding: for a triangle so thin that e1 x e2 itself is noise (the
@@ -1203,48 +1203,9 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree6(TraceArgs a)
 #define PT_CERT_NT_STORE (PT_STREAM_NT != 0)
 #endif
 #endif
-__device__ __forceinline__ h16 round_down_h16(float v)
-{
-    h16 h = (h16)v;
-    if ((float)h > v) {                       /* rounded up (or overflowed to +inf): one step down */
-        uint16_t b = hbits(h);
-        b = (b & 0x8000u) ? (uint16_t)(b + 1u) : (b == 0u ? (uint16_t)0x8001u : (uint16_t)(b - 1u));
-        h = hfrombits(b);
-    }
-    return h;
-}
-
-/* Lower bounds of the ray's entry distance into the two boxes of one interior record.  dx,dy,dz = c - o as box_pair
- * computes them; inv = 1/d in fp32 (finite and non-zero: the caller does not walk other rays).
- * Per axis the box is widened to [c - e, c + e] with e = max(|ha|, |hb|) (1 + 2^-10) + |c - o| 2^-20 + 2^-24, which
- * contains the builder's fp32 box (|true a - (c + ha)| <= |ha| 2^-11, or 2^-25 for a subnormal half, from the digest's
- * rounding) with room for every rounding below; the near plane of that slab lies at (c - o) inv - e |inv|.  The fused
- * multiply-adds here are this bound's own arithmetic, not the reference's. */
-__device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float invx, float invy, float invz,
-                                            h16x2 ax, h16x2 ay, h16x2 az, h16x2 bx, h16x2 by, h16x2 bz, float& boundL, float& boundR)
-{
-    auto axis = [](f32x2 d, float inv, h16x2 ha, h16x2 hb) {
-        const h16x2 eh = __builtin_elementwise_max(as_h2(__builtin_bit_cast(uint32_t, ha) & 0x7FFF7FFFu),
-                                                   as_h2(__builtin_bit_cast(uint32_t, hb) & 0x7FFF7FFFu));
-        const f32x2 e = __builtin_convertvector(eh, f32x2);                                                   /* exact */
-        f32x2 n;
-        const float e0 = __builtin_fmaf(fabsf(d.x), 0x1p-20f, __builtin_fmaf(e.x, 1.0f + 0x1p-10f, 0x1p-24f));
-        const float e1 = __builtin_fmaf(fabsf(d.y), 0x1p-20f, __builtin_fmaf(e.y, 1.0f + 0x1p-10f, 0x1p-24f));
-        n.x = __builtin_fmaf(d.x, inv, -fabsf(e0 * inv));
-        n.y = __builtin_fmaf(d.y, inv, -fabsf(e1 * inv));
-        return n;
-    };
-    const f32x2 nx = axis(dx, invx, ax, bx), ny = axis(dy, invy, ay, by), nz = axis(dz, invz, az, bz);
-    const float eL = fmaxf(fmaxf(nx.x, ny.x), nz.x), eR = fmaxf(fmaxf(nx.y, ny.y), nz.y);
-    /* the products and the reciprocal are off by a few parts in 2^24; PT_CERT_SLACK is far more than that and is there
-       for the triangle test: the t it computes for a triangle inside the box may lie this far (relative) before the
-       point where the ray enters the box and the triangle is still not skipped */
-    boundL = __builtin_fmaf(-fabsf(eL), PT_CERT_SLACK, eL); boundR = __builtin_fmaf(-fabsf(eR), PT_CERT_SLACK, eR);
-}
-
-/* The same lower bounds from the box test's own fp16 values (PT_CERT_BOUND16, default): box_pair with, per axis, the
- * near slab distance min(t0, t1) it computes anyway, less a bound E of everything that separates that fp16 value from the
- * exact (a - o) / d, (b - o) / d of the builder's fp32 box [a, b]:
+/* Lower bounds of the distances at which the ray enters the two boxes of one interior record, from the box test's own
+ * fp16 values: box_pair with, per axis, the near slab distance min(t0, t1) it computes anyway, less a bound E of everything
+ * that separates that fp16 value from the exact (a - o) / d, (b - o) / d of the builder's fp32 box [a, b]:
  *
  *   digest      ha = f16(a - c):  |ha - (a - c)| <= |a - c| (2^-11 + 2^-23), or 2^-25 below the normal range;
  *   origin      nox = f16(c - o): the same for c - o;
@@ -1252,38 +1213,38 @@ __device__ __forceinline__ void entry_bound(f32x2 dx, f32x2 dy, f32x2 dz, float 
  *   direction   rx = f16(1 / d):  (1 / d)(1 + 2^-11 + 2^-24);
  *   product     t = s rx in fp16: 2^-11 relative, or 2^-25 below the normal range.
  *
- * With W = max(|ha|, |hb|) + |nox| that is  |t - T| <= W |rx| 2^-9 (1 + 2^-8) + |rx| 2^-23 (1 + 2^-8) + 2^-25  for both
- * planes of the slab, and  E = (W + 2^-12) k,  k = max(|rx| 2^-8, 2^-10) (a per-ray constant, exact in fp16), is at least
- * twice that, which pays for the three roundings of E itself and for the one of near - E (a single fused operation: this
- * is the bound's own arithmetic, not the reference's).  The entry distance is the largest near-plane distance, and the
- * largest of the three lower bounds is a lower bound of it; where an axis yields NaN or -inf (0 x inf, an overflow) the
- * IEEE maximum leaves it out, which keeps what is left a bound.  An fp16 tmin of +inf (a slab beyond the fp16 range)
- * gives a bound of +inf: the reference's own `max_t > tmin` can never hold for that box either.  About 24 packed
- * operations for both boxes where the fp32 bound takes 43 and 16 more to round its two results down to fp16 for the
- * stack; and the bound is an fp16 value to begin with. */
+ * With H = max(|ha|, |hb|) + |nox| that is  |t - T| <= H |rx| 2^-9 (1 + 2^-8) + |rx| 2^-23 (1 + 2^-8) + 2^-25  for both
+ * planes of the slab, and  E = (|nox| + W) k,  k = max(|rx| 2^-8, 2^-10) (a per-ray constant, exact in fp16),
+ * W >= max(|ha|, |hb|) + 2^-12 (a per-box constant the flattening pass rounds up to fp16: the largest over the three
+ * axes, so that one value serves all of them), is at least twice that, which pays for the two roundings of E itself and
+ * for the one of near - E (a single fused operation: this is the bound's own arithmetic, not the reference's).  The entry
+ * distance is the largest near-plane distance, and the largest of the three lower bounds is a lower bound of it; where an
+ * axis yields NaN or -inf (0 x inf, an overflow) the IEEE maximum leaves it out, which keeps what is left a bound.  An
+ * fp16 tmin of +inf (a slab beyond the fp16 range) gives a bound of +inf: the reference's own `max_t > tmin` can never
+ * hold for that box either.  W = +inf (half extents beyond the fp16 range, or a subtree the flattening pass marks as never
+ * to be skipped on distance) gives -inf or NaN on every axis, and neither compares greater than anything: never skipped.
+ * Thirteen packed operations for both boxes on top of the box test. */
 __device__ __forceinline__ void box_pair_bound(const RayRegs& r, h16x2 rx, h16x2 ry, h16x2 rz, h16x2 kx, h16x2 ky, h16x2 kz,
                                                f32x2 cx, f32x2 cy, f32x2 cz, h16x2 ax, h16x2 ay, h16x2 az, h16x2 bx, h16x2 by, h16x2 bz,
-                                               bool& sL, bool& sR, float& tminL, float& tminR, h16x2& bound)
+                                               h16x2 wmax, bool& sL, bool& sR, float& tminL, float& tminR, h16x2& bound)
 {
-    const h16x2 pad = { (h16)0x1p-12f, (h16)0x1p-12f };
     auto habs = [](h16x2 v) { return as_h2(__builtin_bit_cast(uint32_t, v) & 0x7FFF7FFFu); };
     f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
     h16x2 nox = __builtin_convertvector(dx, h16x2), noy = __builtin_convertvector(dy, h16x2), noz = __builtin_convertvector(dz, h16x2);
     h16x2 t0 = (ax + nox) * rx, t1 = (bx + nox) * rx;
     h16x2 near = __builtin_elementwise_min(t0, t1);
     h16x2 tmin = near, tmax = __builtin_elementwise_max(t0, t1);
-    /* a <= c <= b, so -ha and hb are the magnitudes */
-    bound = __builtin_elementwise_fma(-((__builtin_elementwise_max(-ax, bx) + habs(nox)) + pad), kx, near);
+    bound = __builtin_elementwise_fma(-(habs(nox) + wmax), kx, near);
     t0 = (ay + noy) * ry; t1 = (by + noy) * ry;
     near = __builtin_elementwise_min(t0, t1);
     tmin = __builtin_elementwise_max(tmin, near);
     tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
-    bound = __builtin_elementwise_max(bound, __builtin_elementwise_fma(-((__builtin_elementwise_max(-ay, by) + habs(noy)) + pad), ky, near));
+    bound = __builtin_elementwise_max(bound, __builtin_elementwise_fma(-(habs(noy) + wmax), ky, near));
     t0 = (az + noz) * rz; t1 = (bz + noz) * rz;
     near = __builtin_elementwise_min(t0, t1);
     tmin = __builtin_elementwise_max(tmin, near);
     tmax = __builtin_elementwise_min(tmax, __builtin_elementwise_max(t0, t1));
-    bound = __builtin_elementwise_max(bound, __builtin_elementwise_fma(-((__builtin_elementwise_max(-az, bz) + habs(noz)) + pad), kz, near));
+    bound = __builtin_elementwise_max(bound, __builtin_elementwise_fma(-(habs(noz) + wmax), kz, near));
     const float fminL = (float)tmin.x, fminR = (float)tmin.y, fmaxL = (float)tmax.x, fmaxR = (float)tmax.y;
     sL = (fmaxL > 0.0f || fminL > 0.0f) && fmaxL >= fminL && r.min_t < fmaxL;
     sR = (fmaxR > 0.0f || fminR > 0.0f) && fmaxR >= fminR && r.min_t < fmaxR;
@@ -1302,9 +1263,6 @@ __device__ __forceinline__ h16x2 bound_slack(h16x2 b)
     const h16x2 s = { (h16)(PT_CERT_SLACK * 1.125f), (h16)(PT_CERT_SLACK * 1.125f) };
     return __builtin_elementwise_fma(-as_h2(__builtin_bit_cast(uint32_t, b) & 0x7FFF7FFFu), s, b);
 }
-#ifndef PT_CERT_BOUND16
-#define PT_CERT_BOUND16 1
-#endif
 
 /* MODE_RAYS, MODE_JOBS, or MODE_MIXED: a job list and, behind it, a shadow queue in one pool (see k_trace_flat).  A lane with
  * a shadow ray walks near child first with the reference's own culling and stops at the first hit: nothing about an any-hit
@@ -1323,9 +1281,9 @@ __device__ __forceinline__ h16x2 bound_slack(h16x2 b)
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs a)
 {
-    __shared__ uint32_t sRef[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][64];
-    __shared__ uint16_t sBound[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][64];      /* entry bound of the waiting child, rounded down */
-    __shared__ uint16_t sGate[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][64];       /* largest fp16 tmin from the root down to it */
+    /* per entry and lane two words, 64 words apart (one two-word LDS access each way): [0] the waiting child's reference,
+       [1] its entry bound (low half; fp16) and the largest fp16 tmin from the root down to it (high half) */
+    __shared__ uint32_t sStk[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
@@ -1340,11 +1298,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
     RayRegs r; uint32_t exclude = 0, tag = 0;
     uint32_t id = 0;                      /* a launch has fewer than 2^32 rays: one register, not two */
     h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
-#if PT_CERT_BOUND16
     h16x2 kx = rx, ky = rx, kz = rx;             /* per-axis factors of the entry bound's error term (box_pair_bound) */
-#else
-    float invx = 0, invy = 0, invz = 0;
-#endif
     uint32_t cur = 0; int sp = 0;
     bool hit = false, tie = false, nearLast = false;
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
@@ -1377,12 +1331,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
         limitReg = r.max_t; otherT = __builtin_huge_valf();
         rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
-#if PT_CERT_BOUND16
         kx = bound_factor(r.rcpD.x); ky = bound_factor(r.rcpD.y); kz = bound_factor(r.rcpD.z);
         const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
-#else
-        invx = 1.0f / r.d.x; invy = 1.0f / r.d.y; invz = 1.0f / r.d.z;
-#endif
         /* finite and non-zero, all nine: x - x is 0 exactly then, NaN for an infinity or a NaN */
         const float probe = (invx - invx) + (invy - invy) + (invz - invz) + (r.o.x - r.o.x) + (r.o.y - r.o.y) + (r.o.z - r.o.z) +
                             (r.d.x - r.d.x) + (r.d.y - r.d.y) + (r.d.z - r.d.z);
@@ -1465,28 +1415,16 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
             bool sL, sR; float tminL, tminR;
             const f32x2 cx = as_f2(q0.x, q0.y), cy = as_f2(q0.z, q0.w), cz = as_f2(q1.x, q1.y);
             const h16x2 ax = as_h2(q1.z), ay = as_h2(q1.w), az = as_h2(q2.x), bx = as_h2(q2.y), by = as_h2(q2.z), bz = as_h2(q2.w);
-#if PT_CERT_BOUND16
+            /* the bounds are not used by a lane with a shadow ray (it culls with the reference's test below), and cost it
+               nothing it could skip: they ride in the box test's packed operations */
             h16x2 bound16;
-            box_pair_bound(r, rx, ry, rz, kx, ky, kz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR, bound16);
+            box_pair_bound(r, rx, ry, rz, kx, ky, kz, cx, cy, cz, ax, ay, az, bx, by, bz, as_h2(q3.w), sL, sR, tminL, tminR, bound16);
             bound16 = bound_slack(bound16);
             float boundL = (float)bound16.x, boundR = (float)bound16.y;
-#else
-            box_pair(r, rx, ry, rz, cx, cy, cz, ax, ay, az, bx, by, bz, sL, sR, tminL, tminR);
-            const f32x2 dx = { cx.x - r.o.x, cx.y - r.o.x }, dy = { cy.x - r.o.y, cy.y - r.o.y }, dz = { cz.x - r.o.z, cz.y - r.o.z };
-            float boundL = 0.0f, boundR = 0.0f;
-            /* Shadow rays cull with the reference's test and never use the bounds.  A per-lane branch lets a wavefront
-             * whose lanes all hold shadow rays jump over the arithmetic and keeps the kernel at 83 VGPRs; a wave-wide
-             * vote around the same call took 90, which left no room for the second walk's wavefronts beside this
-             * launch (133 against 157 spp/s on certified frames). */
-            if (!(MODE == MODE_MIXED && shadowLane))
-                entry_bound(dx, dy, dz, invx, invy, invz, ax, ay, az, bx, by, bz, boundL, boundR);
-#endif
             /* enter unless the order-independent part of the reference's verdict fails or the box certainly begins beyond
-               everything that still matters */
+               everything that still matters (a subtree with a triangle too thin for its test to mean anything geometric
+               comes with a bound of -inf or NaN: never skipped on distance) */
             const float reach = fmaxf(r.max_t, hitGate);
-            /* a subtree with a triangle too thin for its test to mean anything geometric is never skipped on distance */
-            if (q3.w & 1u) boundL = NEG_INF;
-            if (q3.w & 2u) boundR = NEG_INF;
             bool pL = sL && !(boundL > reach), pR = sR && !(boundR > reach);
             if (MODE == MODE_MIXED && shadowLane) {       /* the reference's own culling; the stack keeps tmin where the bound would be */
                 pL = sL && r.max_t > tminL; pR = sR && r.max_t > tminR;
@@ -1497,14 +1435,11 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
             if (pL && pR) {
                 const uint32_t second = rightFirst ? refL : refR;
                 const float boundSecond = rightFirst ? boundL : boundR, tminSecond = rightFirst ? tminL : tminR;
-#if PT_CERT_BOUND16
-                const uint16_t bb = hbits((h16)boundSecond);        /* exact: an fp16 value (the bound, or a shadow ray's tmin), or -inf */
-#else
-                const uint16_t bb = hbits(round_down_h16(boundSecond));
-#endif
+                const uint16_t bb = hbits((h16)boundSecond);        /* exact: an fp16 value (the bound, or a shadow ray's tmin) */
                 const uint16_t gb = hbits((h16)fmaxf(pathGate, tminSecond));             /* exact: both came from fp16 values */
-                if (sp < PT_CERT_STACK_LDS) { sRef[wave][sp][lane] = second; sBound[wave][sp][lane] = bb; sGate[wave][sp][lane] = gb; }
-                else a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid] = make_uint2(second, (uint32_t)bb | ((uint32_t)gb << 16));
+                const uint32_t bg = (uint32_t)bb | ((uint32_t)gb << 16);
+                if (sp < PT_CERT_STACK_LDS) { sStk[wave][sp][0][lane] = second; sStk[wave][sp][1][lane] = bg; }
+                else a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid] = make_uint2(second, bg);
                 sp++;
             }
             if (pL || pR) {
@@ -1519,9 +1454,10 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
             if (sp == 0) { done = true; break; }
             sp--;
             const int e = sp < PT_CERT_STACK_LDS ? sp : PT_CERT_STACK_LDS - 1;
-            uint32_t ref = sRef[wave][e][lane]; uint16_t bb = sBound[wave][e][lane], gb = sGate[wave][e][lane];
+            uint32_t ref = sStk[wave][e][0][lane], bg = sStk[wave][e][1][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= PT_CERT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid]; ref = o.x; bb = (uint16_t)o.y; gb = (uint16_t)(o.y >> 16); }
+            if (sp >= PT_CERT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid]; ref = o.x; bg = o.y; }
+            const uint16_t bb = (uint16_t)bg, gb = (uint16_t)(bg >> 16);
             const float waiting = (float)hfrombits(bb);
             const bool enter = (MODE == MODE_MIXED && shadowLane) ? r.max_t > waiting : !(waiting > fmaxf(r.max_t, hitGate));
             if (enter) { cur = ref; pathGate = (float)hfrombits(gb); needPop = false; }
@@ -1542,7 +1478,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
 #undef limit0
 }
 
-/* Self-test of entry_bound, the lemma the certified walk rests on: for random fp32 boxes [a, b] (sizes and offsets over
+/* Self-test of box_pair_bound, the lemma the certified walk rests on: for random fp32 boxes [a, b] (sizes and offsets over
  * twenty octaves, including half extents that are fp16 subnormals or beyond the fp16 range) digested exactly as the
  * flattening pass digests them, and random rays (starting inside, outside, far away; directions down to 1e-6 in a
  * component), the bound never exceeds the distance at which the ray enters [a, b], computed here in fp64.  Counts the
@@ -1602,20 +1538,36 @@ __global__ __launch_bounds__(256) void k_selftest_entry_bound(uint64_t seed, uin
     }
     float boundL, boundR;
     bool unreachable[2] = { false, false };      /* fp16 tmin of +inf: the reference's max_t > tmin never holds, nothing is claimed */
-#if PT_CERT_BOUND16
+    /* the per-box constant as the flattening pass makes it: largest digested half extent + 2^-12, rounded up to fp16 */
+    h16x2 wmax;
+    {
+        uint16_t wb[2];
+        for (int k = 0; k < 2; k++) {
+            double w = 0.0; bool inf = false;
+            for (int x = 0; x < 3; x++) {
+                const h16 lo = k == 0 ? ha[x].x : ha[x].y, hi = k == 0 ? hb[x].x : hb[x].y;
+                const uint16_t ml = hbits(lo) & 0x7FFFu, mh = hbits(hi) & 0x7FFFu;
+                inf = inf || ml >= 0x7C00u || mh >= 0x7C00u;
+                w = fmax(w, fmax((double)(float)hfrombits(ml), (double)(float)hfrombits(mh)));
+            }
+            w += 0x1p-12;
+            h16 rr = (h16)w;
+            uint16_t u = hbits(rr);
+            if ((double)(float)rr < w) u++;
+            wb[k] = inf ? (uint16_t)0x7C00u : u;
+        }
+        wmax = { hfrombits(wb[0]), hfrombits(wb[1]) };
+    }
     {
         RayRegs r; r.o = { o[0], o[1], o[2] }; ray_set_dir(r, { d[0], d[1], d[2] }); r.min_t = 0.0f; r.max_t = __builtin_huge_valf();
         const h16x2 rx = { r.rcpD.x, r.rcpD.x }, ry = { r.rcpD.y, r.rcpD.y }, rz = { r.rcpD.z, r.rcpD.z };
         bool sL, sR; float tL, tR; h16x2 b16;
         box_pair_bound(r, rx, ry, rz, bound_factor(r.rcpD.x), bound_factor(r.rcpD.y), bound_factor(r.rcpD.z), c[0], c[1], c[2],
-                       ha[0], ha[1], ha[2], hb[0], hb[1], hb[2], sL, sR, tL, tR, b16);
+                       ha[0], ha[1], ha[2], hb[0], hb[1], hb[2], wmax, sL, sR, tL, tR, b16);
         boundL = (float)b16.x; boundR = (float)b16.y;
         unreachable[0] = tL == __builtin_huge_valf(); unreachable[1] = tR == __builtin_huge_valf();
         (void)dd;
     }
-#else
-    entry_bound(dd[0], dd[1], dd[2], 1.0f / d[0], 1.0f / d[1], 1.0f / d[2], ha[0], ha[1], ha[2], hb[0], hb[1], hb[2], boundL, boundR);
-#endif
     for (int k = 0; k < 2; k++) {
         double enter = -1e300, leave = 1e300;
         for (int x = 0; x < 3; x++) {
@@ -1625,10 +1577,6 @@ __global__ __launch_bounds__(256) void k_selftest_entry_bound(uint64_t seed, uin
         if (!(enter <= leave) || unreachable[k]) continue;                /* the ray does not reach this box: nothing is claimed */
         atomicAdd(out + 0, 1ull);
         const float bound = k == 0 ? boundL : boundR;
-#if PT_CERT_BOUND16
         if ((double)bound > enter) atomicAdd(out + 1, 1ull);              /* (a NaN bound - every axis overflowed - skips nothing) */
-#else
-        if (!((double)bound <= enter)) atomicAdd(out + 1, 1ull);         /* a NaN bound skips nothing, but would hide a mistake: counted too */
-#endif
     }
 }
