@@ -247,7 +247,7 @@ enum {
                                     passes of the path tracer) are walked near child first with skips that are safe in
                                     any order, and the few rays whose answer that does not prove equal to the
                                     reference's are walked again in reference order - results identical to 0 and 1
-                                    (hits, and with them every buffer of a frame) at 0.85 of the speed
+                                    (hits, and with them every buffer of a frame) at 0.87 of the speed
                                     of 2 for batches and for frames, on the one assumption that the t a triangle test computes lies
                                     where the triangle is (to 2^-7 relative): it fails only where that test's
                                     determinant is lost to rounding, for a ray lying in a triangle's plane to a few

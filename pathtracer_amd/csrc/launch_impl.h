@@ -155,8 +155,9 @@ int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area
     a.overflowEntries = ctx->overflowEntries;
     a.flagList = flag; a.flagCount = ctr;
     a.refillMin = (uint32_t)refill_min(ctx, SHAPE_FRAME);
-    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : small_scene(ctx) ? 3 : 5)), block(PT_BLOCK);      /* small scene: 2 ... 6 -> 402, 415, 402, 383, 382 spp/s; large: 4, 5, 6 -> 159, 169.5, 151.5 (80 VGPRs: a sixth
-                                                                                                                                  workgroup per CU fits, and leaves the other band's passes no room) */
+    /* workgroups per CU, small scene: 2 ... 6 -> 402, 415, 402, 383, 382 spp/s; large: 4, 5, 6 -> 159, 169.5, 151.5 (at 80 VGPRs a
+       sixth fits, and leaves the other band's passes no room) */
+    dim3 grid(ctx->numCUs * (ctx->userBlocks ? ctx->optBlocksPerCU : small_scene(ctx) ? 3 : 5)), block(PT_BLOCK);
     hipLaunchKernelGGL((k_trace_cert<MODE_MIXED, false>), grid, block, 0, stream, a);
     HIPCHK(hipGetLastError());
     TraceArgs b = a;
