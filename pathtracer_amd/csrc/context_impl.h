@@ -117,6 +117,7 @@ struct PtContext {
     uint64_t overflowLanes = 0; int overflowAreas = 0;
     float rootBox[6] = {0}; float rootC[3] = {0}; uint16_t rootH[6] = {0};
     float lastC[3] = {0}; uint16_t lastH[6] = {0};        /* box digest of the reference array's last node */
+    PtSpineBox* dSpine = nullptr; uint32_t spineCount = 0;      /* the path from the last node up to the root's child (certified walk) */
 
     /* per-resolution (bindings 5,6,9,10) */
     uint32_t W = 0, H = 0, slots = 0;
@@ -167,7 +168,7 @@ template <class T> void dfree(T*& p) { if (p) { (void)hipFree(p); p = nullptr; }
 void free_scene(PtContext* c)
 {
     dfree(c->dPositions); dfree(c->dAux); dfree(c->dIndices); dfree(c->dNodes); dfree(c->dLights); dfree(c->dBlueNoise);
-    dfree(c->dRecords); dfree(c->dOverflow); dfree(c->dLeafRef); dfree(c->dTreelets);
+    dfree(c->dRecords); dfree(c->dOverflow); dfree(c->dLeafRef); dfree(c->dTreelets); dfree(c->dSpine); c->spineCount = 0;
     c->treeletBytes = 0; c->treeletMaxStack = 0;
     c->V = c->T = c->N = c->L = 0;
 }
@@ -272,6 +273,7 @@ void fill_trace_args(PtContext* c, TraceArgs& a)
     for (int k = 0; k < 6; k++) a.rootH[k] = c->rootH[k];
     for (int k = 0; k < 3; k++) a.lastC[k] = c->lastC[k];
     for (int k = 0; k < 6; k++) a.lastH[k] = c->lastH[k];
+    a.spine = c->dSpine; a.spineCount = c->spineCount;
     a.rootRef = (c->T == 1) ? PT_LEAF_BIT : 0u;
     a.overflow = c->dOverflow; a.overflowEntries = c->overflowEntries;
     a.refillMin = (uint32_t)c->optRefillMin; a.claimChunk = (uint32_t)c->optClaimChunk;

@@ -220,6 +220,28 @@ try {
         HIPCHK(hipMemcpy(ctx->dTreelets, tl.data(), tl.size(), hipMemcpyHostToDevice));
         ctx->treeletBytes = (uint32_t)((size_t)tlUnits * 64); ctx->treeletMaxStack = tlStack;
     }
+    {
+        /* the nodes from the root's right child down to the last node (each the right child of the one before), stored
+           deepest first; the certified walk redoes their box tests for the few rays that need them */
+        std::vector<PtSpineBox> spine;
+        for (uint32_t i = 0; nodes[i].right > 0 && spine.size() <= PT_SPINE_MAX;) {
+            i = (uint32_t)nodes[i].right;
+            PtSpineBox sb; memset(&sb, 0, sizeof(sb));
+            sb.index = i;
+            for (int k = 0; k < 3; k++) {
+                sb.c[k] = (nodes[i].a[k] + nodes[i].b[k]) * 0.5f;
+                _Float16 ha = (_Float16)(nodes[i].a[k] - sb.c[k]), hb = (_Float16)(nodes[i].b[k] - sb.c[k]);
+                memcpy(&sb.h[k], &ha, 2); memcpy(&sb.h[3 + k], &hb, 2);
+            }
+            spine.insert(spine.begin(), sb);
+        }
+        ctx->spineCount = 0;
+        if (!spine.empty() && spine.size() <= PT_SPINE_MAX && spine.front().index == N - 1) {
+            HIPCHK(hipMalloc((void**)&ctx->dSpine, spine.size() * sizeof(PtSpineBox)));
+            HIPCHK(hipMemcpy(ctx->dSpine, spine.data(), spine.size() * sizeof(PtSpineBox), hipMemcpyHostToDevice));
+            ctx->spineCount = (uint32_t)spine.size();
+        }
+    }
     if (ctx->compact) {
         HIPCHK(hipMalloc((void**)&ctx->dLeafRef, (size_t)T * 4));
         HIPCHK(hipMemcpy(ctx->dLeafRef, leafRef.data(), (size_t)T * 4, hipMemcpyHostToDevice));

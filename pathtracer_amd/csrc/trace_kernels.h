@@ -78,6 +78,16 @@ enum { MODE_RAYS = 0, MODE_JOBS = 1, MODE_SHADOW = 2,
                                (any hit) - the closest-hit pass of one bounce and the shadow pass of the bounce before it, which
                                both wait for the same shade pass and for nothing else, as one launch */
 
+/* One node of the path from the root to the last node of the reference array (always the right child: the nodes whose
+ * skip link is 0), digested like every other box. */
+struct PtSpineBox {
+    float    c[3];
+    uint32_t index;          /* the node's index in the reference array */
+    uint16_t h[6];
+    uint32_t pad;
+};
+#define PT_SPINE_MAX 64
+
 struct TraceArgs {
     /* reference layout */
     const PtBVHNode* nodes;  uint32_t numNodes;
@@ -92,6 +102,8 @@ struct TraceArgs {
     uint32_t         lastLeaf;       /* 48 B records: triangle index of the leaf that is the reference array's last node */
     float            rootC[3]; uint16_t rootH[6]; uint32_t rootRef;
     float            lastC[3]; uint16_t lastH[6];          /* the same digest of the box of the reference array's last node */
+    const PtSpineBox* spine;         /* the nodes from the last node up to (not including) the root, deepest first; see k_trace_cert */
+    uint32_t         spineCount;     /* 0: no table (a path of more than PT_SPINE_MAX nodes) */
     /* treelet layout: records (128 B) and leaves (64 B) in one buffer addressed in 64 B units */
     const uint4*     treelets;
     uint32_t         treeletBytes;
@@ -1302,6 +1314,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
     uint32_t cur = 0; int sp = 0;
     bool hit = false, tie = false, nearLast = false;
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
+    uint32_t hitLeaf = 0;                 /* jobs: the hit leaf's index in the reference array */
     float alpha = 0, beta = 0, gamma = 0;
     float pathGate = 0, hitGate = 0;      /* largest fp16 tmin on the way to the current record / to the hit held */
     float limitReg = 0, otherT = 0;       /* the ray's own max_t (batches; a job's is the constant of trace.comp:190); smallest t of any other triangle the ray was seen to hit */
@@ -1318,10 +1331,10 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         freshShadow = rid >= numJobs;
         return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
     };
-    auto store = [&](bool h) {
-        if (MODE != MODE_MIXED) store_result<MODE, PT_CERT_NT_STORE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
+    auto store = [&](bool h, uint32_t orig) {
+        if (MODE != MODE_MIXED) store_result<MODE, PT_CERT_NT_STORE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
         else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, r.max_t, -1, -1, -1, 0, 0, 0, 0u);
-        else store_result<MODE_JOBS>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, 0u);
+        else store_result<MODE_JOBS>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
     };
 
     auto start_ray = [&](const RayWords& w) {
@@ -1341,16 +1354,16 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         nearLast = false;
         if (MODE == MODE_JOBS || (MODE == MODE_MIXED && !shadowLane)) {
             /* what the shade pass is told besides the hit - whether the reference's walk went on into the last node of
-               its array (intersections.glsl:109-113) - depends on that walk's max_t when it got there.  It cannot have
-               gone in if the order-independent part of that node's box test fails, which is the case for all but a
-               few rays in a million; those few take the second walk */
+               its array and out at its end (intersections.glsl:109-113) - depends on that walk's max_t when it got there.
+               It cannot have gone in if the order-independent part of that node's box test fails; for the other rays the
+               question is settled when the walk is over (ran_off below) */
             nearLast = box_static(r, a.lastC[0], a.lastC[1], a.lastC[2], hfrombits(a.lastH[0]), hfrombits(a.lastH[1]), hfrombits(a.lastH[2]),
                                   hfrombits(a.lastH[3]), hfrombits(a.lastH[4]), hfrombits(a.lastH[5]), ftmin);
         }
         bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
-        if (!walkable) { flag_ray(); store(false); }
+        if (!walkable) { flag_ray(); store(false, 0u); }
         else if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }          /* the root's test is the reference's own: it comes first in every order */
-        else store(false);
+        else store(false, 0u);
     };
 
     for (;;) {
@@ -1408,6 +1421,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
                     if (hit) { if (t == r.max_t) tie = true; otherT = fminf(otherT, r.max_t); }
                     r.max_t = t; hit = true; hitGate = pathGate; alpha = al; beta = be; gamma = ga;
                     hitI1 = (int32_t)q0.w; hitI2 = (int32_t)q1.w; hitI3 = (int32_t)q2.w;
+                    if (MODE != MODE_RAYS) hitLeaf = q3.x;
                 } else otherT = fminf(otherT, t);
             }
         } else {
@@ -1464,8 +1478,32 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         }
 
         if (done) {
-            if (!(MODE == MODE_MIXED && shadowLane) && hit && (tie || nearLast || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
-            store(hit);
+            /* Did the reference's walk run off the end of its array (the hit's leaf is then handed to the shade pass)?  It
+               did if every node on the way from the root to the last node passed its box test when the walk came by; a node
+               that fails there has skip link 0 and ends the walk.  With the certificate in hand (the ray is not listed
+               below) those tests can be redone here: the nodes of that path in front of the hit's leaf X are X's own
+               ancestors, which the reference entered; the ones behind it are reached with X found and nothing accepted
+               since (X is the nearest, a tie is listed), so max_t is t of X there.  The table holds them deepest first: the
+               last node's own box, the smallest, is the likeliest to fail. */
+            uint32_t orig = 0u;
+            bool unsettled = false;
+            if (MODE != MODE_RAYS && !(MODE == MODE_MIXED && shadowLane) && nearLast && hit) {
+                if (a.spineCount == 0u) unsettled = true;
+                else {
+                    bool ran = true;
+                    for (uint32_t k = 0; k < a.spineCount && ran; k++) {
+                        const PtSpineBox sb = a.spine[k];
+                        if (sb.index <= hitLeaf) break;
+                        float tm;
+                        const bool s = box_static(r, sb.c[0], sb.c[1], sb.c[2], hfrombits(sb.h[0]), hfrombits(sb.h[1]), hfrombits(sb.h[2]),
+                                                  hfrombits(sb.h[3]), hfrombits(sb.h[4]), hfrombits(sb.h[5]), tm);
+                        ran = s && r.max_t > tm;
+                    }
+                    if (ran) orig = hitLeaf;
+                }
+            }
+            if (!(MODE == MODE_MIXED && shadowLane) && hit && (tie || unsettled || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
+            store(hit, orig);
             active = false;
         }
         }   /* if (active) */
