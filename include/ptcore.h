@@ -277,8 +277,11 @@ enum {
                                     0 = never, 1 = always, 2 (default) = batches of 2^20 rays or more */
     PT_OPT_SORT_BITS      = 10,  /* 1..4 (default 4): the ordering grid has 2^bits cells per axis */
     PT_OPT_SECOND_WALK    = 11,  /* how PT_OPT_TRAVERSAL = 3 walks the rays its first pass lists, in reference order: 0 = one
-                                    ray per lane (the walk of traversal 1); 1 (default) = one ray per wavefront, 64 nodes of
-                                    the reference array fetched and box-tested at a time.  Same hits, bit for bit */
+                                    ray per lane (the walk of traversal 1); 1 = one ray per wavefront, 64 nodes of the
+                                    reference array fetched and box-tested at a time; 2 (default) = both launches are queued
+                                    and the length of the list, which only the device knows, decides which of them works
+                                    (a short list is all latency and goes one ray to a wavefront, a long one is throughput
+                                    and goes one to a lane).  Same hits, bit for bit */
     PT_OPT_SHADOW_STREAM  = 12,  /* inside pt_render_sample[s], where a bounce's shadow pass is a launch of its own: 1 = on a
                                     second stream beside the closest-hit pass of the next bounce; 0 = on the frame's own
                                     stream, after the shade pass (half as many streams: for hosts short of hardware

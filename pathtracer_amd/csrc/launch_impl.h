@@ -133,8 +133,16 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
     HIPCHK(hipGetLastError());
     TraceArgs b = a;
     b.order = flag; b.countPtr = ctr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
-    if (ctx->optSecondWalk == 0)
-        return launch_trace<MODE, false>(ctx, b, count, stream, area, fixed);    /* traversal 3 maps to the reference-order walk there */
+    /* Few listed rays are all latency - the walk of the longest of them - and go one to a wavefront; many are throughput
+       and go one to a lane (the walk of traversal 1).  How many there are only the device knows, so by default both
+       launches are queued and each looks at the count: the one whose case it is not leaves at once. */
+#ifndef PT_SECOND_WALK_SPLIT
+#define PT_SECOND_WALK_SPLIT 16384
+#endif
+    if (ctx->optSecondWalk == 2) { b.onlyFrom = PT_SECOND_WALK_SPLIT; b.onlyBelow = PT_SECOND_WALK_SPLIT; }
+    if (ctx->optSecondWalk != 1)
+        if (int rc = launch_trace<MODE, false>(ctx, b, count, stream, area, fixed)) return rc;    /* traversal 3 maps to the reference-order walk there */
+    if (ctx->optSecondWalk == 0) return 0;
     /* the listed rays are few and their walks long: one wavefront per ray (k_trace_ref_wave); no stack, no spill area */
 #ifndef PT_WAVE_WALK_BLOCKS
 #define PT_WAVE_WALK_BLOCKS 32        /* a batch lists some ten thousand rays: one per wavefront where the chip holds that many (8 / 16 / 32 per CU: 29.31 / 29.09 / 29.00 ms per 2^26-ray call) */
@@ -162,7 +170,10 @@ int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area
     HIPCHK(hipGetLastError());
     TraceArgs b = a;
     b.order = flag; b.countPtr = ctr; b.countPtr2 = nullptr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
-    if (ctx->optSecondWalk == 0) return launch_trace<MODE_JOBS, false>(ctx, b, false, stream, area);
+    if (ctx->optSecondWalk == 2) { b.onlyFrom = PT_SECOND_WALK_SPLIT; b.onlyBelow = PT_SECOND_WALK_SPLIT; }      /* see launch_cert */
+    if (ctx->optSecondWalk != 1)
+        if (int rc = launch_trace<MODE_JOBS, false>(ctx, b, false, stream, area)) return rc;
+    if (ctx->optSecondWalk == 0) return 0;
     /* one wavefront per workgroup: these find room beside a launch that fills the CUs more easily than groups of four */
     hipLaunchKernelGGL((k_trace_ref_wave<MODE_JOBS, false>), dim3(ctx->numCUs * 8), dim3(64), 0, stream, b);
     HIPCHK(hipGetLastError());

@@ -137,7 +137,12 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
         if (!p.dFlag) HIPCHK(hipMalloc((void**)&p.dFlag, (size_t)ctx->W * ctx->H * 4));
         uint32_t* flagCtr = p.dCtr + ctr_flag_base(ctx->slots) + 2 * depth;
         if (!overlapped) HIPCHK(hipMemsetAsync(flagCtr, 0, 2 * 4, p.stream));          /* overlapped: k_launch cleared them */
-        if (int rc = launch_cert<MODE_JOBS>(ctx, a, false, p.stream, 2 * p.index, p.dFlag, flagCtr)) return rc;
+        if (p.deferredShadow >= 0) {
+            /* the shadow rays the last bounce's shade pass queued ride along (they cull with the reference's own test) */
+            const int d0 = p.deferredShadow;
+            a.shadowRays = p.dShadow[d0 & 1]; a.countPtr2 = p.dCtr + CTR_SHADOW + 2 * d0;
+            if (int rc = launch_cert_mixed(ctx, a, p.stream, 2 * p.index, p.dFlag, flagCtr)) return rc;
+        } else if (int rc = launch_cert<MODE_JOBS>(ctx, a, false, p.stream, 2 * p.index, p.dFlag, flagCtr)) return rc;
     } else if (p.deferredShadow >= 0) {
         /* the shadow rays the last bounce's shade pass queued ride along */
         const int d0 = p.deferredShadow;
@@ -172,8 +177,10 @@ static int trace_depth(PtContext* ctx, FramePipe& p, uint32_t depth, int specula
         return launch_trace<MODE_SHADOW, true>(ctx, s, false, st, area);
     };
     /* merged passes: this bounce's shadow rays wait for the next bounce's closest-hit launch, unless there is none, or that
-       launch is one of the kinds that cannot take them (certified walk, treelets, the reference layout) */
-    const bool mergeable = ctx->optMergePasses && (ctx->optTraversal == 1 || ctx->optTraversal == 2);
+       launch is one of the kinds that cannot take them (the reference layout; the certified walk where it falls back to the
+       reference-order walk) */
+    const bool mergeable = ctx->optMergePasses && (ctx->optTraversal == 1 || ctx->optTraversal == 2 ||
+                                                   (ctx->optTraversal == 3 && !ctx->compact && ctx->boxesNest));
     if (overlapped && mergeable && !speculative && depth + 1 < ctx->consts.numRays) {
         p.deferredShadow = (int)depth;
         return 0;

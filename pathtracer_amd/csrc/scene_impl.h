@@ -90,7 +90,7 @@ PT_API int pt_set_option(PtContext* ctx, int option, int value)
         case PT_OPT_TIME_TRAVERSAL: ctx->optTimeTraversal = value != 0; ctx->travUsed = 0; return 0;
         case PT_OPT_TRAIN_MAX_MB: if (value < 0) return ctx->fail(-1, "PT_OPT_TRAIN_MAX_MB must not be negative"); ctx->optTrainMaxMB = value; return 0;
         case PT_OPT_TRAIN_PARTS: if (value < 1 || value > PT_MAX_TRAIN_PARTS) return ctx->fail(-1, "PT_OPT_TRAIN_PARTS must be 1..4"); ctx->optTrainParts = value; return 0;
-        case PT_OPT_SECOND_WALK: if (value < 0 || value > 1) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0 or 1"); ctx->optSecondWalk = value; return 0;
+        case PT_OPT_SECOND_WALK: if (value < 0 || value > 2) return ctx->fail(-1, "PT_OPT_SECOND_WALK must be 0, 1 or 2"); ctx->optSecondWalk = value; return 0;
         case PT_OPT_FRAMES_IN_FLIGHT: if (value < 1 || value > PT_MAX_PIPES) return ctx->fail(-1, "PT_OPT_FRAMES_IN_FLIGHT must be 1..8"); ctx->optFramesInFlight = value; return 0;
         default: return ctx->fail(-1, "unknown option");
     }

@@ -116,6 +116,10 @@ struct TraceArgs {
     uint64_t         count;
     uint32_t         refillMin;      /* refill a wavefront when this many lanes are idle */
     uint32_t         claimChunk;     /* ids a wavefront takes from the counter at a time (0: chosen from the ray count) */
+    /* second walk of the certified walk: two launches are queued and the list's length, known on the device only, decides
+       which of them works - k_trace_ref_wave leaves at once when the list holds onlyBelow rays or more (0: never),
+       k_trace_flat when it holds fewer than onlyFrom */
+    uint32_t         onlyBelow, onlyFrom;
     /* MODE_RAYS */
     const PtRay*     rays;  PtHit* hits;
     const uint32_t*  order;          /* the k-th ray to trace is rays[order[k]] (nullptr: rays[k]) */
@@ -438,6 +442,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)      /
 {
     const int lane = threadIdx.x & 63;
     const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
+    if (a.onlyBelow && total >= a.onlyBelow) return;        /* a list this long is the one-ray-per-lane launch's */
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
     enum : uint32_t { SUCC_NEXT_WINDOW = 64, SUCC_JUMP = 65, SUCC_END = 66, SUCC_RAN_OFF = 67 };
     /* Everything a wavefront decides here it decides for all its lanes: no lane may leave a loop or skip a block on its
@@ -587,6 +592,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
     const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
     const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
+    if (MODE != MODE_MIXED && total < a.onlyFrom) return;      /* a list this short is the one-ray-per-wavefront launch's */
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.records, 0, (int)a.recordBytes, 0x00020000);
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
@@ -782,6 +788,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
     const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
     const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
+    if (MODE != MODE_MIXED && total < a.onlyFrom) return;      /* a list this short is the one-ray-per-wavefront launch's */
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.treelets, 0, (int)a.treeletBytes, 0x00020000);
 
     RayPool pool; pool.init(a, total, gridDim.x * PT_WAVES_PER_BLOCK);
@@ -990,6 +997,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree6(TraceArgs a)
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
     const uint64_t numJobs = a.countPtr ? (uint64_t)*a.countPtr : a.count;       /* MODE_MIXED: ids below this are jobs, the rest shadow rays */
     const uint64_t total = numJobs + (MODE == MODE_MIXED ? (uint64_t)*a.countPtr2 : 0ull);
+    if (MODE != MODE_MIXED && total < a.onlyFrom) return;      /* a list this short is the one-ray-per-wavefront launch's */
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.treelets, 0, (int)a.treeletBytes, 0x00020000);
     const uint32_t NO_GATE = 0xFC00u;                                   /* -inf: max_t > -inf always holds */
 

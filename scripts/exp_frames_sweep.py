@@ -14,6 +14,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--layout", type=int, default=0)
 ap.add_argument("--slots", default="8")
 ap.add_argument("--bits", type=int, default=4)
+ap.add_argument("--second", type=int, default=-1, help="PT_OPT_SECOND_WALK (traversal 3): 0 = one lane per listed ray, 1 = one wavefront per listed ray; -1 = leave")
 ap.add_argument("--keep", type=int, default=0, help="PT_OPT_TRAIN_KEEP: the train is kept between calls (flushed inside the timed region at the end)")
 ap.add_argument("--percall", type=int, default=0, help="frames per pt_render_samples call (a synchronize after each); 0 = all in one call")
 lists = ("train", "parts", "merge", "blocks", "refill", "inflight")
@@ -44,6 +45,7 @@ for trav, NR in itertools.product([int(v) for v in args.traversal.split(",")], [
         for o, v in ((core.OPT_FRAMES_IN_FLIGHT, inflight), (core.OPT_MERGE_PASSES, merge), (core.OPT_FRAME_TRAIN, train), (core.OPT_TRAIN_PARTS, parts)):
             ctx.set_option(o, v)
         ctx.set_option(core.OPT_TRAIN_KEEP, args.keep)
+        if args.second >= 0: ctx.set_option(core.OPT_SECOND_WALK, args.second)
         if blocks: ctx.set_option(core.OPT_PERSIST_BLOCKS, blocks)
         if refill: ctx.set_option(core.OPT_REFILL_MIN, refill)
         ctx.render_samples(1, 12); ctx.synchronize()

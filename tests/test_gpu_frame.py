@@ -231,7 +231,7 @@ def test_error_behaviour(oracle_lib, bunny):
         for opt, good, bad in ((core.OPT_TRAVERSAL, 1, 4), (core.OPT_PERSIST_BLOCKS, 4, 0), (core.OPT_REFILL_MIN, 20, 65),
                                (core.OPT_CLAIM_CHUNK, 256, 100), (core.OPT_FRAMES_IN_FLIGHT, 4, 9), (core.OPT_RECORD_LAYOUT, 1, 3),
                                (core.OPT_SORT_RAYS, 1, 3), (core.OPT_SORT_BITS, 2, 5), (core.OPT_FRAME_TRAIN, 1, 3), (core.OPT_TRAIN_PARTS, 3, 5),
-                               (core.OPT_TRAIN_MAX_MB, 64, -1), (core.OPT_SHADOW_STREAM, 1, 3), (core.OPT_SECOND_WALK, 0, 2)):
+                               (core.OPT_TRAIN_MAX_MB, 64, -1), (core.OPT_SHADOW_STREAM, 1, 3), (core.OPT_SECOND_WALK, 0, 3)):
             ctx.set_option(opt, good)
             assert ctx.get_option(opt) == good
             with pytest.raises(pt.PtError):

@@ -469,6 +469,37 @@ def test_certified_walk_on_thin_triangles(gpu_ctx, ntri):
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
 
 
+@pytest.mark.parametrize("kind,ntri", [("unit", 40000), ("flat", 40000)])
+def test_second_walk_settings_agree_on_short_and_long_lists(gpu_ctx, kind, ntri):
+    """PT_OPT_SECOND_WALK: one listed ray per lane (0), per wavefront (1), or both launches queued and the list's length
+    deciding on the device (2, the default).  A soup of ordinary triangles lists a handful of rays, which the default sends
+    to the wavefront walk; a soup of coplanar triangles lists most rays that hit anything, which it sends to the lane walk.
+    All three give the reference-order walk's hits, bit for bit."""
+    rng = np.random.default_rng(2026)
+    pos, idx = helpers.triangle_soup(rng, ntri, kind)
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 8)
+    gpu_ctx.upload_scene(pos, np.zeros(pos.shape[0], dtype=pt.AUX_DT), ridx, nodes)
+    n = 1 << 20
+    rays = helpers.random_rays(nodes[0]["a"], nodes[0]["b"], n, seed=ntri + len(kind))
+    try:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT)
+        ref = gpu_ctx.trace_rays(rays)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+        listed = {}
+        for second in (0, 1, 2):
+            gpu_ctx.set_option(core.OPT_SECOND_WALK, second)
+            got, st = gpu_ctx.trace_rays(rays, want_stats=True)
+            assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), f"second walk {second}"
+            listed[second] = int(st[3]) - n
+        # every setting walks each listed ray exactly once more (the default's idle launch walks none)
+        assert listed[0] == listed[1] == listed[2], listed
+        if gpu_ctx.get_option(core.OPT_RECORD_LAYOUT) == 0:      # (48 B records: the reference-order walk throughout, nothing is listed)
+            assert (listed[2] < 16384) == (kind == "unit"), listed
+    finally:
+        gpu_ctx.set_option(core.OPT_SECOND_WALK, 2)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+
+
 def test_entry_bound_never_exceeds_the_true_entry_distance(gpu_ctx):
     """The lemma under the certified walk, checked where it is computed: 2^26 random boxes and rays on the device, the
     bound against the fp64 entry distance into the builder's box."""
