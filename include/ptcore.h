@@ -242,16 +242,18 @@ PT_API void*       pt_stream(PtContext* ctx);          /* the context's hipStrea
 /* Options (no reference counterpart; they select among documented behaviours). */
 enum {
     PT_OPT_TRAVERSAL      = 1,   /* 0 = reference 32 B nodes, stackless walk; 1 = PtNode2, reference visit
-                                    order (results identical to 0); 2 = PtNode2, near child first (default);
-                                    3 = certified walk: closest-hit rays (batches of pt_trace_rays and the closest-hit
-                                    passes of the path tracer) are walked near child first with skips that are safe in
-                                    any order, and the few rays whose answer that does not prove equal to the
-                                    reference's are walked again in reference order - results identical to 0 and 1
-                                    (hits, and with them every buffer of a frame) at 0.87 of the speed
-                                    of 2 for batches and for frames, on the one assumption that the t a triangle test computes lies
-                                    where the triangle is (to 2^-7 relative): it fails only where that test's
-                                    determinant is lost to rounding, for a ray lying in a triangle's plane to a few
-                                    parts in 10^7.  Needs 64 B records and a tree whose boxes nest (every
+                                    order (results identical to 0); 2 = PtNode2, near child first: the fastest walk,
+                                    1.15 times the speed of 3, whose closest hit differs from the reference's on about
+                                    one ray in 10^5 (the reference's fp16 box test is not conservative, so its answer
+                                    depends on its visit order);
+                                    3 (default) = certified walk: closest-hit rays (batches of pt_trace_rays and the
+                                    closest-hit passes of the path tracer) are walked near child first with skips that
+                                    are safe in any order, and the few rays whose answer that does not prove equal to
+                                    the reference's are walked again in reference order - results identical to 0 and 1
+                                    (hits, and with them every buffer of a frame), on the one assumption that the t a
+                                    triangle test computes lies where the triangle is (to 2^-7 relative): it fails only
+                                    where that test's determinant is lost to rounding, for a ray lying in a triangle's
+                                    plane to a few parts in 10^7.  Needs 64 B records and a tree whose boxes nest (every
                                     pt_build_bvh tree), else 3 is served by the reference-order walk; any-hit rays
                                     get the near-first walk, whose verdict no order changes */
     PT_OPT_STALE_SLOTS    = 2,   /* 0 = zero prob of the next slot when a path ends (default); 1 = leave
@@ -289,7 +291,7 @@ enum {
     PT_OPT_MERGE_PASSES   = 13,  /* inside pt_render_sample[s]: 1 (default) = the shadow rays of bounce d are traced by the same
                                     launch as the closest-hit rays of bounce d + 1 (both wait for the shade pass of d only):
                                     half the launches, one stream per frame, and a frame rate that no longer hinges on the
-                                    number of hardware queues; needs traversal 1 or 2, otherwise the passes stay apart.
+                                    number of hardware queues; needs traversal 1, 2 or 3 on flattened records (the reference layout keeps the passes apart).
                                     Results do not depend on it */
     PT_OPT_FRAME_TRAIN    = 14,  /* pt_render_sample[s]: 0 = never, 1 = wherever it can serve, 2 (default) = where it can serve and
                                     numRays >= 3 or the scene's traversal records exceed 8 MiB (a small scene with one bounce
@@ -330,8 +332,8 @@ enum {
     PT_OPT_FRAMES_IN_FLIGHT = 7  /* 1..8 (default 3): frames the per-frame pipeline keeps in flight (PT_OPT_FRAME_TRAIN = 0, and what
                                     the frame train does not serve), each on its own ray stack and stream; results do not
                                     depend on it.  With merged passes three frames are three streams and HIP's default of
-                                    four hardware queues per process is enough.  Where the passes stay apart (traversal 3,
-                                    treelet records) every frame in flight has a second stream; with four queues, six
+                                    four hardware queues per process is enough.  Where the passes stay apart (the reference
+                                    layout, traversal 3 where it falls back to the reference-order walk) every frame in flight has a second stream; with four queues, six
                                     streams share queues and wait on each other (about a fifth fewer frames per second at
                                     1080p).  A host that renders that way should export GPU_MAX_HW_QUEUES=8 (2 per frame in
                                     flight plus 2; never above 32) before its first HIP call - the library cannot set it

@@ -50,6 +50,7 @@ OPT_SECOND_WALK = 11            # certified walk's second pass: 0 = a ray per la
 OPT_RECORD_LAYOUT = 8           # 0 = 64 B records, 1 = 48 B records, 2 = 128 B treelet records beside the 64 B ones
 LAYOUT_RECORDS64, LAYOUT_RECORDS48, LAYOUT_TREELETS = 0, 1, 2
 TRAVERSAL_REFERENCE_LAYOUT, TRAVERSAL_FLAT, TRAVERSAL_FLAT_ORDERED, TRAVERSAL_CERTIFIED = 0, 1, 2, 3
+TRAVERSAL_DEFAULT = TRAVERSAL_CERTIFIED          # what a new context starts with
 
 
 class PtError(RuntimeError):

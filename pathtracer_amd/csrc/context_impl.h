@@ -136,7 +136,7 @@ struct PtContext {
     uint64_t sortCapacity = 0;
 
     PtShaderConstants consts; bool haveConsts = false;
-    int optTraversal = 2, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 2, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 2, optTrainParts = 2, optTrainMaxMB = 0, optTrainKeep = 0;
+    int optTraversal = 3, optStale = 0, optReseed = 0, optBlocksPerCU = 5, optRefillMin = 36, optClaimChunk = 0, optFramesInFlight = 3, optRecordLayout = 0, optSortRays = 2, optSortBits = 4, optSecondWalk = 2, optShadowStream = 2, optMergePasses = 1, optFrameTrain = 2, optTrainParts = 2, optTrainMaxMB = 0, optTrainKeep = 0;
     bool userBlocks = false, userRefill = false;      /* PT_OPT_PERSIST_BLOCKS / PT_OPT_REFILL_MIN were set by the caller */
     float lastMs = 0.0f; bool evPending = false;
     /* PT_OPT_TIME_TRAVERSAL: an event pair around every traversal launch of the frame train, read by pt_traversal_ms */

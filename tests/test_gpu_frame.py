@@ -210,6 +210,9 @@ def test_ordered_traversal_image_rmse(gpu_ctx, oracle_lib, monkey):
 def test_error_behaviour(oracle_lib, bunny):
     ctx = pt.PathTracer(0)
     try:
+        # a new context starts with the walk whose results are the reference's
+        assert ctx.get_option(core.OPT_TRAVERSAL) == core.TRAVERSAL_DEFAULT == core.TRAVERSAL_CERTIFIED
+        assert ctx.get_option(core.OPT_SECOND_WALK) == 2
         with pytest.raises(pt.PtError):
             ctx.launch()                                   # nothing uploaded
         with pytest.raises(pt.PtError):
@@ -239,7 +242,7 @@ def test_error_behaviour(oracle_lib, bunny):
             assert ctx.get_option(opt) == good
         with pytest.raises(pt.PtError):
             ctx.set_option(99, 0)
-        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
         with pytest.raises(pt.PtError):
             ctx.set_constants(pt.fill_constants(64, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0] + 2))   # wrong node count
         ctx.set_constants(pt.fill_constants(64, 64, 2, bunny["indices"].shape[0], bunny["nodes"].shape[0]))
@@ -874,7 +877,7 @@ def test_cpp_host_renders_what_the_python_host_renders(gpu_ctx, bunny, tmp_path)
         assert (out / f"RayStackBuffer_{NF}.bin.z").exists() and (out / "pt_host.ppm").stat().st_size > W * H * 3
     assert hashes["sites"] == hashes["batch"] == hashes["kept"]
     _setup(gpu_ctx, bunny, W, H, NR)
-    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)      # the library's default, which the C++ host runs with
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)      # the library's default, which the C++ host runs with
     for frame in range(1, NF + 1):
         gpu_ctx.set_constants(_consts(bunny, W, H, NR, frame, BUNNY_CAM))
         gpu_ctx.render_sample(frame)

@@ -231,7 +231,7 @@ def test_full_size_microbench_properties(gpu_ctx):
         assert (near["t"][near["i1"] < 0] == rays["max_t"][0]).all()        # a miss returns the interval's end
     finally:
         d_rays.free(); d_a.free(); d_b.free()
-        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 @pytest.mark.parametrize("traversal", [core.TRAVERSAL_FLAT, core.TRAVERSAL_FLAT_ORDERED])
@@ -265,7 +265,7 @@ def test_ray_ordering_changes_nothing(gpu_ctx, bunny, traversal):
                 assert np.array_equal(plain.view(np.uint8), ordered.view(np.uint8)), f"{name}, any_hit={any_hit}"
     finally:
         ctx.set_option(core.OPT_SORT_RAYS, 2)
-        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 @pytest.mark.parametrize("traversal", [core.TRAVERSAL_FLAT_ORDERED, core.TRAVERSAL_CERTIFIED])
@@ -315,7 +315,7 @@ def test_back_to_back_batches_equal_one_at_a_time(gpu_ctx, courtyard_small, trav
         for r, h, _ in bufs:
             r.free(); h.free()
         ctx.set_option(core.OPT_SORT_RAYS, 2)
-        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 @pytest.mark.parametrize("kind", ["unit", "flat", "sliver", "offset", "huge"])
@@ -341,7 +341,7 @@ def test_random_triangle_soups_exact(gpu_ctx, oracle_lib, kind):
         gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
         near = gpu_ctx.trace_rays(rays)
         assert np.array_equal(near["i1"] >= 0, hits["i1"] >= 0)
-    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+    gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 def test_deep_stacks_spill_past_the_lds_part(gpu_ctx, oracle_lib):
@@ -380,7 +380,7 @@ def test_deep_stacks_spill_past_the_lds_part(gpu_ctx, oracle_lib):
         st = gpu_ctx.trace_rays(rays[: m // 2], want_stats=True)[1]
         assert st[0] / (m // 2) > 2 * n * 0.9          # the corner rays really test nearly every box
     finally:
-        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 def test_certified_walk_equals_reference_order_at_scale(gpu_ctx):
@@ -430,7 +430,7 @@ def test_certified_walk_equals_reference_order_at_scale(gpu_ctx):
             assert int(st[3]) - n < n // 50
     finally:
         gpu_ctx.set_option(core.OPT_SORT_RAYS, 2)
-        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
         d_rays.free(); d_hits.free()
 
 
@@ -466,7 +466,7 @@ def test_certified_walk_on_thin_triangles(gpu_ctx, ntri):
         got = gpu_ctx.trace_rays(rays)
         assert np.array_equal(got.view(np.uint8), ref.view(np.uint8))
     finally:
-        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 @pytest.mark.parametrize("kind,ntri", [("unit", 40000), ("flat", 40000)])
@@ -497,7 +497,7 @@ def test_second_walk_settings_agree_on_short_and_long_lists(gpu_ctx, kind, ntri)
             assert (listed[2] < 16384) == (kind == "unit"), listed
     finally:
         gpu_ctx.set_option(core.OPT_SECOND_WALK, 2)
-        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_FLAT_ORDERED)
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
 
 
 def test_entry_bound_never_exceeds_the_true_entry_distance(gpu_ctx):
