@@ -7,7 +7,10 @@ config "SanMiguel.ply 64M random incoherent rays, pure traversal microbench vs H
 One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE).  A step is one
 pass of pt_trace_rays over 2^26 synthetic rays per GPU that are already resident in HBM: the library
 builds an order for the batch by origin cell (a counting sort of indices, three small kernels) and
-traces the rays in that order; both are timed.
+traces the rays in that order; both are timed.  The walk is the library's default, the certified walk
+(PT_OPT_TRAVERSAL = 3), whose hits are the reference-order walk's bit for bit: a first pass near child
+first and a second, in reference order, over the rays the first lists; extra.near_first_walk is the
+same batch under the faster walk that differs from the reference's on about one ray in 10^5.
 The scene is replicated on every GPU and every rank traces its own range of the ray sequence, so
 the path has no data exchange: weak scaling, value = rays of all ranks / max-over-ranks time.
 
@@ -20,9 +23,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                  HBM peak; the algorithmic bytes the walk asks for are reported beside it (requested_GBps),
   cpu_baseline - the CPU oracle in reference-faithful mode timed on a bounded sample of the same
                  rays on this box's host cores (N = 1 only),
-  extra        - measured outside the timed region, for context: the certified and any-hit walks on the same rays, spp/s
+  extra        - measured outside the timed region, for context: the near-first and any-hit walks on the same rays, spp/s
                  of the full wavefront path tracer (1080p and 4K x 8 bounces on the SanMiguel and sponza stand-ins,
-                 CBbunny primary + 1 bounce); with N > 1 the sample-partitioned render and its all-reduce instead.
+                 CBbunny primary + 1 bounce; library defaults, and the SanMiguel frames under the near-first walk as
+                 well); with N > 1 the sample-partitioned render and its all-reduce instead.
 """
 import argparse
 import json
@@ -174,7 +178,7 @@ def main():
     st = ctx.trace_rays_device(d_rays, nprefix, d_hits, want_stats=True)
     box_per_ray, tri_per_ray, rec_per_ray = (float(st[k]) / nprefix for k in range(3))
     bytes_per_ray = 32.0 + 16.0 + 64.0 * rec_per_ray          # records are counted in 64 B units, whatever the layout
-    kernel_name = {0: "k_trace_ref<MODE_RAYS>", 3: "k_trace_cert<MODE_RAYS>"}.get(
+    kernel_name = {0: "k_trace_ref<MODE_RAYS>", 3: "k_trace_cert<MODE_RAYS> + second walk of the listed rays"}.get(
         args.traversal if args.traversal >= 0 else ctx.get_option(core.OPT_TRAVERSAL), "k_trace_flat<MODE_RAYS>")
 
     def barrier():
@@ -301,13 +305,14 @@ def main():
 
     single = rank == 0 and world == 1 and not args.no_extra
     if single:
-        extra_item("certified_walk", lambda: certified_walk(ctx, d_rays, d_hits, n, trav))
+        extra_item("near_first_walk" if trav == 3 else "certified_walk", lambda: other_walk(ctx, d_rays, d_hits, n, trav))
         extra_item("any_hit", lambda: any_hit_walk(ctx, d_rays, d_hits, n))
     d_rays.free(); d_hits.free()
     if single:
         extra_item("san_miguel_stand_in", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], per_call=True))
         extra_item("san_miguel_stand_in_4k", lambda: path_tracer_spp(ctx, ridx.shape[0], nodes.shape[0], 3840, 2160, 96))
-        extra_item("san_miguel_stand_in_certified_frames", lambda: certified_frames(ctx, ridx.shape[0], nodes.shape[0]))
+        extra_item("san_miguel_stand_in_near_first_frames" if ctx.get_option(core.OPT_TRAVERSAL) == 3 else "san_miguel_stand_in_certified_frames",
+                   lambda: other_walk_frames(ctx, ridx.shape[0], nodes.shape[0]))
 
         def sponza():
             spos, saux, sidx = pt.scenes.sponza_like()
@@ -421,10 +426,11 @@ def cpu_baseline(pos, aux, ridx, nodes, d_rays, budget_s):
     return out
 
 
-def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
-    """Context number: the same batch with PT_OPT_TRAVERSAL = 3, whose hits are the reference-order walk's bit for bit,
-    timed like the headline (whole calls, ordering pass included), and compared on the device with the hits of the
-    reference-order walk (= 1) and of the headline's walk."""
+def other_walk(ctx, d_rays, d_hits, n, headline_traversal):
+    """Context number: the same batch under the other of the two production walks - the near-first walk (PT_OPT_TRAVERSAL = 2)
+    when the headline is the certified walk (= 3, the library default), the certified walk otherwise - timed like the headline
+    (whole calls, ordering pass included); and, compared on the device, on how many rays each of the two differs from the
+    reference-order walk (= 1)."""
     import torch
     from pathtracer_amd import core
 
@@ -438,9 +444,10 @@ def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
         ctx.synchronize()
         return torch.as_tensor(_Alias(buf.ptr, n * 16), device=torch.device("cuda", ctx.device_id)).view(-1, 4)
 
+    alt = 2 if headline_traversal == 3 else 3
     other = ctx.alloc(n * 16)
     try:
-        ctx.set_option(core.OPT_TRAVERSAL, 3)
+        ctx.set_option(core.OPT_TRAVERSAL, alt)
         for _ in range(2):
             ctx.trace_rays_device(d_rays, n, d_hits)
         ctx.synchronize()
@@ -450,17 +457,17 @@ def certified_walk(ctx, d_rays, d_hits, n, headline_traversal):
             ctx.trace_rays_device(d_rays, n, d_hits)
         ctx.synchronize()
         dt = time.perf_counter() - t
-        cert = hits_of(3, d_hits)
+        mine = hits_of(alt, d_hits)
         ref = hits_of(1, other)
-        differ_ref = int((cert != ref).any(dim=1).sum().item())
-        fast = hits_of(headline_traversal, other)
-        differ_fast = int((fast != cert).any(dim=1).sum().item())
+        differ_alt = int((mine != ref).any(dim=1).sum().item())
+        head = hits_of(headline_traversal, d_hits)
+        differ_head = int((head != ref).any(dim=1).sum().item())
     finally:
         ctx.set_option(core.OPT_TRAVERSAL, headline_traversal)
         other.free()
-    return {"Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
-            "rays_whose_hit_differs_from_the_reference_order_walk": differ_ref,
-            "rays_whose_hit_differs_in_the_headline_walk": differ_fast, "rays": n}
+    return {"traversal": alt, "Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3),
+            "rays_whose_hit_differs_from_the_reference_order_walk": differ_alt,
+            "rays_whose_hit_differs_from_the_reference_order_walk_in_the_headline_walk": differ_head, "rays": n}
 
 
 def any_hit_walk(ctx, d_rays, d_hits, n, steps=5):
@@ -479,22 +486,26 @@ def any_hit_walk(ctx, d_rays, d_hits, n, steps=5):
     return {"Mrays_per_s": round(n * steps / dt / 1e6, 1), "ms_per_step": round(dt / steps * 1e3, 3), "occluded_share_of_first_2^20": round(occluded, 4), "rays": n}
 
 
-def certified_frames(ctx, num_triangles, num_nodes):
-    """Context number: the path tracer under PT_OPT_TRAVERSAL = 3 at 1080p x 8 bounces, and whether its accumulation after
-    six frames from a cleared buffer is, byte for byte, that of the reference-order walk (= 1) and of the default (= 2)."""
+def other_walk_frames(ctx, num_triangles, num_nodes):
+    """Context number: the path tracer at 1080p x 8 bounces under the other of the two production walks (near-first when the
+    library default is the certified walk, the certified walk otherwise), and on how many pixels the accumulation after six
+    frames from a cleared buffer differs, byte for byte, from that of the reference-order walk (= 1) - under that walk and
+    under the default."""
     import pathtracer_amd as pt
     from pathtracer_amd import core
     W, H, NR, nf = 1920, 1080, 8, 240
+    default = ctx.get_option(core.OPT_TRAVERSAL)
+    alt = 2 if default == 3 else 3
     ctx.resize(W, H, NR)
     ctx.set_constants(pt.fill_constants(W, H, NR, num_triangles, num_nodes, **pt.scenes.COURTYARD_CAMERA))
     acc = {}
     try:
-        for trav in (3, 1, 2):
+        for trav in (alt, 1, default):
             ctx.set_option(core.OPT_TRAVERSAL, trav)
             ctx.clear_accumulation()
             ctx.render_samples(1, 6)
             acc[trav] = ctx.readback_accumulation()
-        ctx.set_option(core.OPT_TRAVERSAL, 3)
+        ctx.set_option(core.OPT_TRAVERSAL, alt)
         ctx.render_samples(7, NR + 1)
         ctx.synchronize()
         t = time.perf_counter()
@@ -503,11 +514,11 @@ def certified_frames(ctx, num_triangles, num_nodes):
         dt = time.perf_counter() - t
         roof = frame_roofline(ctx, num_triangles, W, H, NR, nf)
     finally:
-        ctx.set_option(core.OPT_TRAVERSAL, 2)
+        ctx.set_option(core.OPT_TRAVERSAL, default)
     differ = lambda a, b: int((a.view(np.uint32) != b.view(np.uint32)).any(axis=2).sum())
-    out = {"spp_per_s_1080p": round(nf / dt, 2), "frames_timed": nf,
-           "pixels_differing_from_the_reference_order_walk_after_6_frames": differ(acc[3], acc[1]),
-           "pixels_differing_in_the_default_walk_after_6_frames": differ(acc[2], acc[1]), "pixels": W * H}
+    out = {"traversal": alt, "spp_per_s_1080p": round(nf / dt, 2), "frames_timed": nf,
+           "pixels_differing_from_the_reference_order_walk_after_6_frames": differ(acc[alt], acc[1]),
+           "pixels_differing_from_the_reference_order_walk_after_6_frames_in_the_default_walk": differ(acc[default], acc[1]), "pixels": W * H}
     if roof:
         out["roofline"] = roof
     return out

@@ -21,9 +21,10 @@ try:
               f"bytes/ray {bj['roofline']['bytes_per_ray']}, achieved {bj['roofline']['achieved']} GB/s", ""]
 except Exception as e:
     lines += ["", f"(no bench line: {e})", ""]
-lines += ["## PMC passes (per dispatch of the traversal kernel over 2^26 rays; mean over dispatches)", "",
-          "| counter | mean per dispatch |", "|---|---|"]
-vals = {}
+lines += ["## PMC passes (per dispatch of each traversal kernel of a step over 2^26 rays; mean over dispatches)", ""]
+# one table per kernel: a step of the certified walk is two or three launches (first pass, second walk of the listed rays by
+# wavefront, and the launch that would walk a long list by lane and leaves at once otherwise)
+per_kernel = defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "bench_counter_collection.csv"))):
     acc = defaultdict(list)
     for r in csv.DictReader(open(f)):
@@ -31,19 +32,24 @@ for f in sorted(glob.glob(os.path.join(src, "pmc*", "bench_counter_collection.cs
             continue
         if int(r["Grid_Size"]) < 100000:
             continue
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    # keep only the full-size dispatches (the counting prefix launch is smaller in time but same grid: drop the first)
-    for k, v in acc.items():
-        v = v[1:] if len(v) > 1 else v
-        vals[k] = sum(v) / len(v)
-        lines.append(f"| {k} | {vals[k]:.6g} |")
-lines.append("")
+        acc[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (kn, k), v in acc.items():
+        # the counting build of the prefix launch is a template instance of its own; of the plain instance every dispatch counts
+        per_kernel[kn][k] = (sum(v) / len(v), len(v))
+vals = defaultdict(float)
+for kn in sorted(per_kernel):
+    lines += [f"### `{kn}`", "", "| counter | mean per dispatch | dispatches |", "|---|---|---|"]
+    for k, (m, cnt) in sorted(per_kernel[kn].items()):
+        lines.append(f"| {k} | {m:.6g} | {cnt} |")
+        if ", true>" not in kn and "true, false>" not in kn.replace(" ", "")[-14:]:
+            vals[k] += m
+    lines.append("")
+lines += ["Sums over the kernels of one step (counting builds left out):", ""]
 if "FETCH_SIZE" in vals:
-    lines.append(f"FETCH_SIZE is reported in KiB-like units of 1 KB: {vals['FETCH_SIZE']:.4g} -> {vals['FETCH_SIZE']*1024/1e9:.2f} GB per launch as reported.")
+    lines.append(f"FETCH_SIZE {vals['FETCH_SIZE']:.6g} KB, WRITE_SIZE {vals.get('WRITE_SIZE', 0):.6g} KB per step; bytes past the L2 = 2 x FETCH_SIZE + WRITE_SIZE = "
+                 f"{(2 * vals['FETCH_SIZE'] + vals.get('WRITE_SIZE', 0)) * 1024 / 1e9:.2f} GB per step (gfx950 tallies a 128 B fabric read as 64 B).")
 if "TCC_HIT_sum" in vals and "TCC_MISS_sum" in vals:
     lines.append(f"L2 hit rate = TCC_HIT/(TCC_HIT+TCC_MISS) = {vals['TCC_HIT_sum']/(vals['TCC_HIT_sum']+vals['TCC_MISS_sum']):.3f}")
-if "SQ_ACTIVE_INST_VALU" in vals and "SQ_BUSY_CYCLES" in vals:
-    pass
 os.makedirs("profiles", exist_ok=True)
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
