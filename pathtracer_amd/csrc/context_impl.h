@@ -243,7 +243,8 @@ int grid_blocks(PtContext* c) { return c->numCUs * (c->optBlocksPerCU > 7 || c->
 uint32_t spill_entries(const PtContext* c)
 {
     const uint32_t deepest = c->maxStack > c->treeletMaxStack ? c->maxStack : c->treeletMaxStack;
-    const uint32_t inLds = PT_CERT_STACK_LDS < PT_STACK_LDS ? PT_CERT_STACK_LDS : PT_STACK_LDS;      /* the kernel that keeps the fewest entries in LDS spills the most */
+    uint32_t inLds = PT_CERT_STACK_LDS < PT_STACK_LDS ? PT_CERT_STACK_LDS : PT_STACK_LDS;      /* the kernel that keeps the fewest entries in LDS spills the most */
+    if (PT_CERT_STACK_LDS_RAYS < inLds) inLds = PT_CERT_STACK_LDS_RAYS;
     return deepest > inLds ? deepest - inLds : 0;
 }
 

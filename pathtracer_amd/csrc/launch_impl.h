@@ -19,6 +19,11 @@ int launch_trace(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, i
 {
     const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
     int blocks = ctx->numCUs * blocks_per_cu(ctx, shape);
+    /* the batch kernel takes 72 VGPRs and 22.5 KB of LDS per workgroup: seven workgroups per CU, which an ordered batch uses
+       (workgroups x idle lanes at refill -> ms per 2^26 rays: 6 x 8 / 10 / 14 / 20: 27.91 / 27.59 / 27.40 / 27.52;
+       7 x 10 / 14 / 20 / 24 / 28: 27.55 / 27.00 / 26.67 / 26.83 / 27.26; 8 x 20: 26.65) */
+    const bool wide = MODE == MODE_RAYS && shape == SHAPE_ORDERED_BATCH;
+    if (wide && !ctx->userBlocks) blocks = ctx->numCUs * 7;
     if (fixed && fixed->maxBlocks) {
         a.overflow = fixed->spill; a.overflowEntries = fixed->spillEntries;
         if (blocks > fixed->maxBlocks) blocks = fixed->maxBlocks;
@@ -115,6 +120,11 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
 {
     const int shape = MODE != MODE_RAYS ? SHAPE_FRAME : (a.order ? SHAPE_ORDERED_BATCH : SHAPE_BATCH);
     int blocks = ctx->numCUs * blocks_per_cu(ctx, shape);
+    /* the batch kernel takes 72 VGPRs and 22.5 KB of LDS per workgroup: seven workgroups per CU, which an ordered batch uses
+       (workgroups x idle lanes at refill -> ms per 2^26 rays: 6 x 8 / 10 / 14 / 20: 27.91 / 27.59 / 27.40 / 27.52;
+       7 x 10 / 14 / 20 / 24 / 28: 27.55 / 27.00 / 26.67 / 26.83 / 27.26; 8 x 20: 26.65) */
+    const bool wide = MODE == MODE_RAYS && shape == SHAPE_ORDERED_BATCH;
+    if (wide && !ctx->userBlocks) blocks = ctx->numCUs * 7;
     if (fixed && fixed->maxBlocks) {
         a.overflow = fixed->spill; a.overflowEntries = fixed->spillEntries;
         if (blocks > fixed->maxBlocks) blocks = fixed->maxBlocks;
@@ -124,9 +134,10 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
         a.overflowEntries = ctx->overflowEntries;
     }
     a.flagList = flag; a.flagCount = ctr;
-    /* a step of this walk is half again as long as the near-first walk's, so idle lanes cost more and are refilled sooner:
-       batches at 4 / 8 / 12 / 16 / 24 idle lanes -> 2 094 / 2 170 / 2 165 / 2 138 / 2 067 Mrays/s */
-    a.refillMin = (uint32_t)(MODE == MODE_RAYS && !ctx->userRefill ? 10 : refill_min(ctx, shape));
+    /* a step of this walk is longer than the near-first walk's, so idle lanes cost more and are refilled sooner (six
+       workgroups per CU wide, as an unordered batch is: 4 / 8 / 12 / 16 / 24 idle lanes -> 2 094 / 2 170 / 2 165 / 2 138 /
+       2 067 Mrays/s); seven wide, later again (above) */
+    a.refillMin = (uint32_t)(MODE == MODE_RAYS && !ctx->userRefill ? (wide ? 20 : 10) : refill_min(ctx, shape));
     dim3 grid(blocks), block(PT_BLOCK);
     if (count) hipLaunchKernelGGL((k_trace_cert<MODE, true>), grid, block, 0, stream, a);
     else hipLaunchKernelGGL((k_trace_cert<MODE, false>), grid, block, 0, stream, a);

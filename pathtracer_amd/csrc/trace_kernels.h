@@ -1290,6 +1290,9 @@ __device__ __forceinline__ h16x2 bound_slack(h16x2 b)
 #ifndef PT_CERT_STACK_LDS
 #define PT_CERT_STACK_LDS PT_STACK_LDS
 #endif
+#ifndef PT_CERT_STACK_LDS_RAYS
+#define PT_CERT_STACK_LDS_RAYS 11     /* batches: seven workgroups of 22.5 KB fit a CU's 160 KB, seven of 24.5 KB do not */
+#endif
 #ifndef PT_CERT_LEAF_MIN
 #define PT_CERT_LEAF_MIN 8       /* batches: lanes at a leaf wait for this many before the triangle tests run (4 / 8 / 12 / 16: 28.8 / 28.4 / 28.4 / 28.7 ms; 1 = never wait: 29.3) */
 #endif
@@ -1303,7 +1306,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
 {
     /* per entry and lane two words, 64 words apart (one two-word LDS access each way): [0] the waiting child's reference,
        [1] its entry bound (low half; fp16) and the largest fp16 tmin from the root down to it (high half) */
-    __shared__ uint32_t sStk[PT_WAVES_PER_BLOCK][PT_CERT_STACK_LDS][2][64];
+    constexpr int STK = MODE == MODE_RAYS ? PT_CERT_STACK_LDS_RAYS : PT_CERT_STACK_LDS;        /* entries of a lane's stack held in LDS */
+    __shared__ uint32_t sStk[PT_WAVES_PER_BLOCK][STK][2][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * PT_BLOCK + threadIdx.x;
     const uint64_t totalLanes = (uint64_t)gridDim.x * PT_BLOCK;
@@ -1317,8 +1321,9 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
     uint32_t pendIdx = 0;
     RayRegs r; uint32_t exclude = 0, tag = 0;
     uint32_t id = 0;                      /* a launch has fewer than 2^32 rays: one register, not two */
-    h16x2 rx = { (h16)0.0f, (h16)0.0f }, ry = rx, rz = rx;
-    h16x2 kx = rx, ky = rx, kz = rx;             /* per-axis factors of the entry bound's error term (box_pair_bound) */
+    /* per axis one register: f16(1 / d) in the low half, the factor k of the entry bound's error term (box_pair_bound) in the
+       high half; the packed operations take either half for both of theirs */
+    h16x2 rkx = { (h16)0.0f, (h16)0.0f }, rky = rkx, rkz = rkx;
     uint32_t cur = 0; int sp = 0;
     bool hit = false, tie = false, nearLast = false;
     int32_t hitI1 = -1, hitI2 = -1, hitI3 = -1;
@@ -1351,8 +1356,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         if (COUNT) { nRay++; nBox++; }
         hit = false; tie = false; sp = 0; pathGate = NEG_INF; hitGate = NEG_INF;
         limitReg = r.max_t; otherT = __builtin_huge_valf();
-        rx = { r.rcpD.x, r.rcpD.x }; ry = { r.rcpD.y, r.rcpD.y }; rz = { r.rcpD.z, r.rcpD.z };
-        kx = bound_factor(r.rcpD.x); ky = bound_factor(r.rcpD.y); kz = bound_factor(r.rcpD.z);
+        rkx = { r.rcpD.x, bound_factor(r.rcpD.x).x }; rky = { r.rcpD.y, bound_factor(r.rcpD.y).x }; rkz = { r.rcpD.z, bound_factor(r.rcpD.z).x };
         const float invx = 1.0f / r.d.x, invy = 1.0f / r.d.y, invz = 1.0f / r.d.z;
         /* finite and non-zero, all nine: x - x is 0 exactly then, NaN for an infinity or a NaN */
         const float probe = (invx - invx) + (invy - invy) + (invz - invz) + (r.o.x - r.o.x) + (r.o.y - r.o.y) + (r.o.z - r.o.z) +
@@ -1440,6 +1444,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
             /* the bounds are not used by a lane with a shadow ray (it culls with the reference's test below), and cost it
                nothing it could skip: they ride in the box test's packed operations */
             h16x2 bound16;
+            const h16x2 rx = { rkx.x, rkx.x }, ry = { rky.x, rky.x }, rz = { rkz.x, rkz.x };
+            const h16x2 kx = { rkx.y, rkx.y }, ky = { rky.y, rky.y }, kz = { rkz.y, rkz.y };
             box_pair_bound(r, rx, ry, rz, kx, ky, kz, cx, cy, cz, ax, ay, az, bx, by, bz, as_h2(q3.w), sL, sR, tminL, tminR, bound16);
             bound16 = bound_slack(bound16);
             float boundL = (float)bound16.x, boundR = (float)bound16.y;
@@ -1460,8 +1466,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
                 const uint16_t bb = hbits((h16)boundSecond);        /* exact: an fp16 value (the bound, or a shadow ray's tmin) */
                 const uint16_t gb = hbits((h16)fmaxf(pathGate, tminSecond));             /* exact: both came from fp16 values */
                 const uint32_t bg = (uint32_t)bb | ((uint32_t)gb << 16);
-                if (sp < PT_CERT_STACK_LDS) { sStk[wave][sp][0][lane] = second; sStk[wave][sp][1][lane] = bg; }
-                else a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid] = make_uint2(second, bg);
+                if (sp < STK) { sStk[wave][sp][0][lane] = second; sStk[wave][sp][1][lane] = bg; }
+                else a.overflow[(size_t)(sp - STK) * totalLanes + gid] = make_uint2(second, bg);
                 sp++;
             }
             if (pL || pR) {
@@ -1475,10 +1481,10 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         while (needPop) {
             if (sp == 0) { done = true; break; }
             sp--;
-            const int e = sp < PT_CERT_STACK_LDS ? sp : PT_CERT_STACK_LDS - 1;
+            const int e = sp < STK ? sp : STK - 1;
             uint32_t ref = sStk[wave][e][0][lane], bg = sStk[wave][e][1][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= PT_CERT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_CERT_STACK_LDS) * totalLanes + gid]; ref = o.x; bg = o.y; }
+            if (sp >= STK) { uint2 o = a.overflow[(size_t)(sp - STK) * totalLanes + gid]; ref = o.x; bg = o.y; }
             const uint16_t bb = (uint16_t)bg, gb = (uint16_t)(bg >> 16);
             const float waiting = (float)hfrombits(bb);
             const bool enter = (MODE == MODE_MIXED && shadowLane) ? r.max_t > waiting : !(waiting > fmaxf(r.max_t, hitGate));
