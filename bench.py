@@ -602,7 +602,7 @@ def frame_roofline(ctx, num_triangles, W, H, NR, nf):
                 rec = r
     except (OSError, KeyError, ValueError):
         pass
-    out = {"bound": "hbm", "kernel": "k_trace_cert<MODE_MIXED> + second walk" if trav == 3 else "k_trace_flat<MODE_MIXED>" if not layout == 2 else "k_trace_tree<MODE_MIXED>",
+    out = {"bound": "hbm", "kernel": "k_trace_cert<MODE_MIXED> (first pass; a short list's second walk runs inside the shade launch, a long one's is in this figure)" if trav == 3 else "k_trace_flat<MODE_MIXED>" if not layout == 2 else "k_trace_tree<MODE_MIXED>",
            "kernel_ms_per_band_step": round(kernel_ms, 3), "bands": parts, "launches_timed": launches, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "traffic": None, "achieved": None, "frac": None, "l2_hit_rate": None, "valu_busy": None, "floor_ratio": None}
     if rec:

@@ -319,25 +319,22 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(FrameArgs f, uint32_t 
  * loop's invariants - light, ambient colour, constants - in vector registers: 72 of them, one wavefront per SIMD beside the
  * other band's traversal launch; one trip per workgroup takes 54, two wavefronts per SIMD there: 194.3 -> 195.9 spp/s.)  Ray
  * counts are kept per depth (each job knows its own): per workgroup in LDS, one global atomic per depth and workgroup at the end. */
-__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_train(FrameArgs f)
+/* Under the certified walk the launch also is the second walk of a short list: its first walkBlocks workgroups take the
+ * jobs the first pass listed, four each, one to a wavefront (wave_walk_ray: the reference-order walk, its answer written
+ * into the job's hit record with the `listed` mark left on), and shade them then and there, one lane per job; the ordinary
+ * workgroups skip the jobs that carry the mark.  A list's walk is all latency - the dependent fetches of its longest ray -
+ * and in a launch of its own it stood between the traversal launch and this one; here it runs beside the shading of
+ * everything else.  A long list (a.onlyBelow jobs or more) has been walked one job to a lane by a launch before this one,
+ * which writes its answers without the mark: the walking workgroups then leave at once and every job is shaded in place. */
+template <bool WALK>        /* false: no walking workgroups (walkBlocks = 0), and the registers of the plain shade pass: 54 instead of 58 */
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_train(FrameArgs f, TraceArgs a, uint32_t walkBlocks)
 {
     __shared__ uint32_t shCount[3][PT_SHADE_BLOCK / 64];
     __shared__ uint32_t shBase[2];
     __shared__ uint32_t shDepth[2][PT_MAX_TRAIN_DEPTH];
     const int lane = threadIdx.x & 63;
-    const uint32_t njobs = f.ctr[TC_NJOBS];
-    if (blockIdx.x * PT_SHADE_BLOCK >= njobs) return;                      /* the same for every thread of a workgroup */
-    for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) (&shDepth[0][0])[k] = 0;
-    __syncthreads();
-    {
-        const uint32_t j = blockIdx.x * PT_SHADE_BLOCK + threadIdx.x;
-        const uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
-        const bool live = slot != PT_JOB_DEAD;
-        bool wantShadow = false;
-        uint32_t nextJob = PT_JOB_DEAD, depth = 0;
-        PtShadowRay sr;
-        shade_job<true>(f, j, slot, live, wantShadow, nextJob, sr, depth);
-        /* a wavefront's jobs are of one or two depths: one LDS atomic per depth present */
+    /* one wavefront's jobs are of a few depths: one LDS atomic per depth present */
+    auto count_depths = [&](bool live, uint32_t depth, bool wantShadow) {
         uint64_t todo = __ballot(live);
         while (todo) {
             const int first = __ffsll((unsigned long long)todo) - 1;
@@ -347,13 +344,58 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_train(FrameArgs f)
             if (lane == first && d < PT_MAX_TRAIN_DEPTH) { atomicAdd(&shDepth[0][d], (uint32_t)__popcll(same)); if (sh) atomicAdd(&shDepth[1][d], (uint32_t)__popcll(sh)); }
             todo &= ~same;
         }
+    };
+    auto flush_depths = [&]() {
+        for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) {
+            const uint32_t c = (&shDepth[0][0])[k];
+            if (c) atomicAdd(f.rayCounts + 2 * (k % PT_MAX_TRAIN_DEPTH) + k / PT_MAX_TRAIN_DEPTH, (unsigned long long)c);
+        }
+    };
+    if (WALK && blockIdx.x < walkBlocks) {
+        const uint32_t listed = *a.countPtr;                                /* the same for every thread of the launch */
+        if (blockIdx.x * (PT_SHADE_BLOCK / 64) >= listed || (a.onlyBelow && listed >= a.onlyBelow)) return;      /* a workgroup per four listed jobs */
+        __builtin_amdgcn_s_setprio(3);                                       /* the launch lasts as long as the longest of these walks */
+        for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) (&shDepth[0][0])[k] = 0;
+        __syncthreads();
+        unsigned long long n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        {   /* one trip per workgroup, as for the ordinary workgroups (a loop would keep the shading's invariants in registers across the walk) */
+            const uint32_t k = blockIdx.x * (PT_SHADE_BLOCK / 64) + wave;
+            const bool have = k < listed;                                    /* the same for the whole wavefront */
+            const uint32_t j = have ? a.order[k] : 0u;
+            if (have) wave_walk_ray<MODE_JOBS, false>(a, j, 1u, n0, n1, n2, n3);
+            const bool live = have && lane == 0;                            /* every lane wrote the record; one shades the job */
+            const uint32_t slot = live ? f.jobs[j] : PT_JOB_DEAD;
+            bool wantShadow = false;
+            uint32_t nextJob = PT_JOB_DEAD, depth = 0;
+            PtShadowRay sr;
+            shade_job<true>(f, j, slot, live, wantShadow, nextJob, sr, depth);
+            count_depths(live, depth, wantShadow);
+            shade_emit(f, j, live, wantShadow, nextJob, sr, shCount, shBase);
+            __syncthreads();
+        }
+        flush_depths();
+        return;
+    }
+    const uint32_t njobs = f.ctr[TC_NJOBS];
+    const uint32_t block = blockIdx.x - (WALK ? walkBlocks : 0u);
+    if (block * PT_SHADE_BLOCK >= njobs) return;                           /* the same for every thread of a workgroup */
+    for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) (&shDepth[0][0])[k] = 0;
+    __syncthreads();
+    {
+        const uint32_t j = block * PT_SHADE_BLOCK + threadIdx.x;
+        const uint32_t slot = (j < njobs) ? f.jobs[j] : PT_JOB_DEAD;
+        bool live = slot != PT_JOB_DEAD;
+        if (WALK && live && f.hitRecs[j].listed) live = false;               /* a walking workgroup's job */
+        bool wantShadow = false;
+        uint32_t nextJob = PT_JOB_DEAD, depth = 0;
+        PtShadowRay sr;
+        shade_job<true>(f, j, slot, live, wantShadow, nextJob, sr, depth);
+        count_depths(live, depth, wantShadow);
         shade_emit(f, j, live, wantShadow, nextJob, sr, shCount, shBase);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 2 * PT_MAX_TRAIN_DEPTH; k += PT_SHADE_BLOCK) {
-        const uint32_t c = (&shDepth[0][0])[k];
-        if (c) atomicAdd(f.rayCounts + 2 * (k % PT_MAX_TRAIN_DEPTH) + k / PT_MAX_TRAIN_DEPTH, (unsigned long long)c);
-    }
+    flush_depths();
 }
 
 /* Ends a step of the frame train; one thread.  The list the shade pass appended to becomes the next step's list (a frame

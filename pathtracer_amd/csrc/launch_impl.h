@@ -167,7 +167,9 @@ int launch_cert(PtContext* ctx, TraceArgs& a, bool count, hipStream_t stream, in
 
 /* The frame train's launch under traversal 3: the certified walk over the step's jobs, with the shadow rays of the step before
  * riding along, then the reference-order walk over the jobs it listed. */
-int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, uint32_t* flag, uint32_t* ctr)
+/* walkInShade: the caller's shade launch walks a short list itself (k_shade_train), so only the launch for a long list is
+ * queued here; *second then holds what that shade launch needs to know of the list. */
+int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area, uint32_t* flag, uint32_t* ctr, bool walkInShade = false, TraceArgs* second = nullptr)
 {
     if (int rc = ensure_overflow(ctx)) return rc;
     a.overflow = ctx->dOverflow ? ctx->dOverflow + (size_t)area * ctx->overflowEntries * ctx->overflowLanes : nullptr;
@@ -182,9 +184,10 @@ int launch_cert_mixed(PtContext* ctx, TraceArgs& a, hipStream_t stream, int area
     TraceArgs b = a;
     b.order = flag; b.countPtr = ctr; b.countPtr2 = nullptr; b.fetchCounter = ctr + 1; b.flagList = nullptr; b.flagCount = nullptr;
     if (ctx->optSecondWalk == 2) { b.onlyFrom = PT_SECOND_WALK_SPLIT; b.onlyBelow = PT_SECOND_WALK_SPLIT; }      /* see launch_cert */
+    if (second) *second = b;
     if (ctx->optSecondWalk != 1)
         if (int rc = launch_trace<MODE_JOBS, false>(ctx, b, false, stream, area)) return rc;
-    if (ctx->optSecondWalk == 0) return 0;
+    if (ctx->optSecondWalk == 0 || walkInShade) return 0;
     /* one wavefront per workgroup: these find room beside a launch that fills the CUs more easily than groups of four */
     hipLaunchKernelGGL((k_trace_ref_wave<MODE_JOBS, false>), dim3(ctx->numCUs * 8), dim3(64), 0, stream, b);
     HIPCHK(hipGetLastError());

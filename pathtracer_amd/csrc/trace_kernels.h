@@ -62,7 +62,10 @@ struct PtHitRec {
     uint16_t bary[3];            /* f16(gamma, alpha, beta), intersections.glsl:49 */
     uint16_t _pad0;
     uint32_t origBvhId;          /* what traceRay leaves in r.origBvhId (intersections.glsl:113) */
-    uint32_t _pad1;
+    uint32_t listed;             /* certified walk: 1 = the job is on the list for the second, reference-order walk and this record
+                                    is not its answer yet (a second walk that is a launch of its own writes the answer with 0 here;
+                                    the frame train's shade pass, which walks a short list itself, leaves the 1 and skips the job
+                                    in its ordinary workgroups) */
 };
 
 /* A next-event-estimation ray, 48 B (trace.comp:95-100 / 111-116). */
@@ -214,7 +217,7 @@ __device__ __forceinline__ bool load_ray(const TraceArgs& a, uint64_t id, RayReg
 
 template <int MODE, bool NT = (PT_STREAM_NT != 0)>
 __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, uint32_t tag, bool hit, float t, int32_t i1, int32_t i2, int32_t i3,
-                                             float alpha, float beta, float gamma, uint32_t origBvhId)
+                                             float alpha, float beta, float gamma, uint32_t origBvhId, uint32_t listed = 0u)
 {
     if (MODE == MODE_RAYS) {
         float4 o;
@@ -227,7 +230,7 @@ __device__ __forceinline__ void store_result(const TraceArgs& a, uint64_t id, ui
         o0.y = (uint32_t)(hit ? i1 : -1); o0.z = (uint32_t)(hit ? i2 : -1); o0.w = (uint32_t)(hit ? i3 : -1);
         o1.x = (uint32_t)hbits((h16)gamma) | ((uint32_t)hbits((h16)alpha) << 16);
         o1.y = (uint32_t)hbits((h16)beta);
-        o1.z = origBvhId; o1.w = 0;
+        o1.z = origBvhId; o1.w = listed;      /* PtHitRec.listed */
         uint4* p = (uint4*)(a.hitRecs + id);
         p[0] = o0; p[1] = o1;
     } else {
@@ -437,6 +440,93 @@ __global__ __launch_bounds__(64) void k_trace_ref_speculative_shadow(TraceArgs a
  * redone from the node behind it with the boxes and triangle results already in registers.  When the path leaves the
  * window the next 64 nodes are fetched from where it went.  Node for node this is the loop of intersections.glsl:64-111
  * with the arithmetic of k_trace_ref; closest hit only, rays from a.order (the list) or in batch order. */
+/* One ray, walked by the whole wavefront (every lane calls this with the same id and leaves with the same result stored by
+ * every lane); `listed` goes into the hit record of a job (PtHitRec.listed). */
+template <int MODE, bool COUNT>      /* MODE_RAYS or MODE_JOBS */
+__device__ __forceinline__ void wave_walk_ray(const TraceArgs& a, uint64_t id, uint32_t listed,
+                                              unsigned long long& nBox, unsigned long long& nTri, unsigned long long& nRec, unsigned long long& nRay)
+{
+    const int lane = threadIdx.x & 63;
+    enum : uint32_t { SUCC_NEXT_WINDOW = 64, SUCC_JUMP = 65, SUCC_END = 66, SUCC_RAN_OFF = 67 };
+    RayRegs r; uint32_t exclude = 0, tag = 0;
+    if (load_ray<MODE>(a, id, r, exclude, tag)) {                   /* the same for all lanes: one ray per wavefront */
+    if (COUNT) nRay++;
+    uint32_t index = 0, hitIndex = 0;
+    bool hit = false, ranOff = false, ended = false;
+    int32_t i1 = -1, i2 = -1, i3 = -1; float alpha = 0, beta = 0, gamma = 0;
+
+    /* every window moves the walk forward by at least one node, every redone chase by at least one lane, every chase
+       step by at least one lane: the three loops end by themselves, and are bounded besides so that a malformed
+       array cannot hold a wavefront for ever */
+    for (uint32_t windows = 0; !ended && windows < a.numNodes; windows++) {
+        const uint32_t base = index, n = base + (uint32_t)lane;
+        const bool valid = n < a.numNodes;
+        float4 na = make_float4(0, 0, 0, 0), nb = na;
+        if (valid) { const float4* np = (const float4*)(a.nodes + n); na = np[0]; nb = np[1]; }
+        if (COUNT) nRec++;
+        float tmin = 0.0f;
+        bool s = false;
+        if (valid) {
+            const float cx = (na.x + nb.x) * 0.5f, cy = (na.y + nb.y) * 0.5f, cz = (na.z + nb.z) * 0.5f;
+            s = box_static(r, cx, cy, cz, (h16)(na.x - cx), (h16)(na.y - cy), (h16)(na.z - cz), (h16)(nb.x - cx), (h16)(nb.y - cy), (h16)(nb.z - cz), tmin);
+        }
+        const int32_t right = __float_as_int(nb.w);
+        const uint32_t nextAbs = (uint32_t)__float_as_int(na.w);
+        const uint64_t leafBits = __ballot(valid && right <= 0);
+        uint64_t triDone = 0;
+        float t = 0, al = 0, be = 0, ga = 0; bool ok0 = false; int32_t v1 = -1, v2 = -1, v3 = -1;
+        uint32_t p = 0;
+        for (int redo = 0; redo <= 64; redo++) {
+            /* where the walk goes from each node of the window, with the max_t of now */
+            const bool pass = s && r.max_t > tmin;
+            uint32_t succ;
+            if (pass) succ = (n + 1u >= a.numNodes) ? (uint32_t)SUCC_RAN_OFF : (uint32_t)lane + 1u;
+            else if (nextAbs == 0u) succ = SUCC_END;
+            else succ = (nextAbs - base < 64u) ? nextAbs - base : (uint32_t)SUCC_JUMP;
+            uint64_t visited = 0;
+            uint32_t q = p, last = p;
+            for (int hop = 0; hop < 64 && q < 64u; hop++) { visited |= 1ull << q; last = q; q = (uint32_t)__builtin_amdgcn_readlane((int)succ, (int)q); }
+            if (COUNT) nBox += (unsigned long long)__popcll(visited);
+            /* the leaves on that path test their triangles, each in its own lane; results are kept for a redone chase */
+            const uint64_t leafVisited = visited & leafBits & __ballot(pass);
+            const uint64_t need = leafVisited & ~triDone;
+            if ((need >> lane) & 1ull) {
+                const uint32_t tri = (uint32_t)(-right) / 3u;
+                const uint4* tp = a.tris + (size_t)tri * 4;
+                const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
+                F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
+                F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
+                RayRegs open = r; open.max_t = __builtin_huge_valf();           /* acceptance against max_t is decided in walk order below */
+                ok0 = tri_test(open, p1, e1, e2, t, al, be, ga);
+                v1 = (int32_t)q0.w; v2 = (int32_t)q1.w; v3 = (int32_t)q2.w;
+            }
+            if (COUNT) nTri += (unsigned long long)__popcll(need);
+            triDone |= need;
+            const uint64_t accept = __ballot(((leafVisited >> lane) & 1ull) && ok0 && t <= r.max_t);
+            if (accept == 0) {                                     /* nothing on the path changes max_t: the walk leaves the window */
+                if (q == SUCC_NEXT_WINDOW) index = base + 64u;
+                else if (q == SUCC_JUMP) index = (uint32_t)__builtin_amdgcn_readlane((int)nextAbs, (int)last);
+                else { ended = true; ranOff = q == SUCC_RAN_OFF; }
+                break;
+            }
+            const int l = __ffsll((unsigned long long)accept) - 1;            /* the first leaf, in walk order, that the reference accepts */
+            r.max_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t), l));
+            alpha = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(al), l));
+            beta = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(be), l));
+            gamma = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ga), l));
+            i1 = __builtin_amdgcn_readlane(v1, l); i2 = __builtin_amdgcn_readlane(v2, l); i3 = __builtin_amdgcn_readlane(v3, l);
+            hit = true; hitIndex = base + (uint32_t)l;
+            /* the leaf's box passed, so the walk goes on at the node behind it, now with the smaller max_t */
+            if (base + (uint32_t)l + 1u >= a.numNodes) { ended = true; ranOff = true; break; }
+            p = (uint32_t)l + 1u;
+            if (p >= 64u) { index = base + 64u; break; }
+        }
+    }
+    store_result<MODE>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, ranOff ? hitIndex : 0u, listed);
+    }
+}
+
 template <int MODE, bool COUNT>      /* MODE_RAYS or MODE_JOBS */
 __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)      /* any whole number of wavefronts per workgroup up to four */
 {
@@ -444,7 +534,6 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)      /
     const uint64_t total = a.countPtr ? (uint64_t)*a.countPtr : a.count;
     if (a.onlyBelow && total >= a.onlyBelow) return;        /* a list this long is the one-ray-per-lane launch's */
     unsigned long long nBox = 0, nTri = 0, nRec = 0, nRay = 0;
-    enum : uint32_t { SUCC_NEXT_WINDOW = 64, SUCC_JUMP = 65, SUCC_END = 66, SUCC_RAN_OFF = 67 };
     /* Everything a wavefront decides here it decides for all its lanes: no lane may leave a loop or skip a block on its
        own, or the votes and lane reads below would run without it (a version that let lane 0 alone claim the ray and
        store the result had the compiler send the other 63 lanes round the loop without it).  Hence rays are dealt to
@@ -457,83 +546,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_ref_wave(TraceArgs a)      /
     const uint32_t firstRay = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * wavesPerBlock + (threadIdx.x >> 6)));
     for (uint64_t k = firstRay; k < total; k += numWaves) {
         const uint64_t id = a.order ? (uint64_t)a.order[k] : k;
-        RayRegs r; uint32_t exclude = 0, tag = 0;
-        if (load_ray<MODE>(a, id, r, exclude, tag)) {                   /* the same for all lanes: one ray per wavefront */
-        if (COUNT) nRay++;
-        uint32_t index = 0, hitIndex = 0;
-        bool hit = false, ranOff = false, ended = false;
-        int32_t i1 = -1, i2 = -1, i3 = -1; float alpha = 0, beta = 0, gamma = 0;
-
-        /* every window moves the walk forward by at least one node, every redone chase by at least one lane, every chase
-           step by at least one lane: the three loops end by themselves, and are bounded besides so that a malformed
-           array cannot hold a wavefront for ever */
-        for (uint32_t windows = 0; !ended && windows < a.numNodes; windows++) {
-            const uint32_t base = index, n = base + (uint32_t)lane;
-            const bool valid = n < a.numNodes;
-            float4 na = make_float4(0, 0, 0, 0), nb = na;
-            if (valid) { const float4* np = (const float4*)(a.nodes + n); na = np[0]; nb = np[1]; }
-            if (COUNT) nRec++;
-            float tmin = 0.0f;
-            bool s = false;
-            if (valid) {
-                const float cx = (na.x + nb.x) * 0.5f, cy = (na.y + nb.y) * 0.5f, cz = (na.z + nb.z) * 0.5f;
-                s = box_static(r, cx, cy, cz, (h16)(na.x - cx), (h16)(na.y - cy), (h16)(na.z - cz), (h16)(nb.x - cx), (h16)(nb.y - cy), (h16)(nb.z - cz), tmin);
-            }
-            const int32_t right = __float_as_int(nb.w);
-            const uint32_t nextAbs = (uint32_t)__float_as_int(na.w);
-            const uint64_t leafBits = __ballot(valid && right <= 0);
-            uint64_t triDone = 0;
-            float t = 0, al = 0, be = 0, ga = 0; bool ok0 = false; int32_t v1 = -1, v2 = -1, v3 = -1;
-            uint32_t p = 0;
-            for (int redo = 0; redo <= 64; redo++) {
-                /* where the walk goes from each node of the window, with the max_t of now */
-                const bool pass = s && r.max_t > tmin;
-                uint32_t succ;
-                if (pass) succ = (n + 1u >= a.numNodes) ? (uint32_t)SUCC_RAN_OFF : (uint32_t)lane + 1u;
-                else if (nextAbs == 0u) succ = SUCC_END;
-                else succ = (nextAbs - base < 64u) ? nextAbs - base : (uint32_t)SUCC_JUMP;
-                uint64_t visited = 0;
-                uint32_t q = p, last = p;
-                for (int hop = 0; hop < 64 && q < 64u; hop++) { visited |= 1ull << q; last = q; q = (uint32_t)__builtin_amdgcn_readlane((int)succ, (int)q); }
-                if (COUNT) nBox += (unsigned long long)__popcll(visited);
-                /* the leaves on that path test their triangles, each in its own lane; results are kept for a redone chase */
-                const uint64_t leafVisited = visited & leafBits & __ballot(pass);
-                const uint64_t need = leafVisited & ~triDone;
-                if ((need >> lane) & 1ull) {
-                    const uint32_t tri = (uint32_t)(-right) / 3u;
-                    const uint4* tp = a.tris + (size_t)tri * 4;
-                    const uint4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                    F3 p1 = { __uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z) };
-                    F3 e1 = { __uint_as_float(q1.x), __uint_as_float(q1.y), __uint_as_float(q1.z) };
-                    F3 e2 = { __uint_as_float(q2.x), __uint_as_float(q2.y), __uint_as_float(q2.z) };
-                    RayRegs open = r; open.max_t = __builtin_huge_valf();           /* acceptance against max_t is decided in walk order below */
-                    ok0 = tri_test(open, p1, e1, e2, t, al, be, ga);
-                    v1 = (int32_t)q0.w; v2 = (int32_t)q1.w; v3 = (int32_t)q2.w;
-                }
-                if (COUNT) nTri += (unsigned long long)__popcll(need);
-                triDone |= need;
-                const uint64_t accept = __ballot(((leafVisited >> lane) & 1ull) && ok0 && t <= r.max_t);
-                if (accept == 0) {                                     /* nothing on the path changes max_t: the walk leaves the window */
-                    if (q == SUCC_NEXT_WINDOW) index = base + 64u;
-                    else if (q == SUCC_JUMP) index = (uint32_t)__builtin_amdgcn_readlane((int)nextAbs, (int)last);
-                    else { ended = true; ranOff = q == SUCC_RAN_OFF; }
-                    break;
-                }
-                const int l = __ffsll((unsigned long long)accept) - 1;            /* the first leaf, in walk order, that the reference accepts */
-                r.max_t = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(t), l));
-                alpha = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(al), l));
-                beta = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(be), l));
-                gamma = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ga), l));
-                i1 = __builtin_amdgcn_readlane(v1, l); i2 = __builtin_amdgcn_readlane(v2, l); i3 = __builtin_amdgcn_readlane(v3, l);
-                hit = true; hitIndex = base + (uint32_t)l;
-                /* the leaf's box passed, so the walk goes on at the node behind it, now with the smaller max_t */
-                if (base + (uint32_t)l + 1u >= a.numNodes) { ended = true; ranOff = true; break; }
-                p = (uint32_t)l + 1u;
-                if (p >= 64u) { index = base + 64u; break; }
-            }
-        }
-        store_result<MODE>(a, id, tag, hit, r.max_t, i1, i2, i3, alpha, beta, gamma, ranOff ? hitIndex : 0u);
-        }
+        wave_walk_ray<MODE, COUNT>(a, id, 0u, nBox, nTri, nRec, nRay);
     }
     if (COUNT && lane == 0) {
         atomicAdd(a.stats + 0, nBox); atomicAdd(a.stats + 1, nTri); atomicAdd(a.stats + 2, nRec); atomicAdd(a.stats + 3, nRay);
@@ -1344,10 +1357,10 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
         freshShadow = rid >= numJobs;
         return freshShadow ? issue_ray<MODE_SHADOW>(a, rid - numJobs, w) : issue_ray<MODE_JOBS>(a, rid, w);
     };
-    auto store = [&](bool h, uint32_t orig) {
-        if (MODE != MODE_MIXED) store_result<MODE, PT_CERT_NT_STORE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
+    auto store = [&](bool h, uint32_t orig, bool listed) {       /* listed: the ray is on the list for the second walk (PtHitRec.listed) */
+        if (MODE != MODE_MIXED) store_result<MODE, PT_CERT_NT_STORE>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig, listed ? 1u : 0u);
         else if (shadowLane) store_result<MODE_SHADOW>(a, id - numJobs, tag, h, r.max_t, -1, -1, -1, 0, 0, 0, 0u);
-        else store_result<MODE_JOBS>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig);
+        else store_result<MODE_JOBS>(a, id, tag, h, r.max_t, hitI1, hitI2, hitI3, alpha, beta, gamma, orig, listed ? 1u : 0u);
     };
 
     auto start_ray = [&](const RayWords& w) {
@@ -1373,9 +1386,9 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
                                   hfrombits(a.lastH[3]), hfrombits(a.lastH[4]), hfrombits(a.lastH[5]), ftmin);
         }
         bool s = box_static(r, a.rootC[0], a.rootC[1], a.rootC[2], rAx, rAy, rAz, rBx, rBy, rBz, ftmin);
-        if (!walkable) { flag_ray(); store(false, 0u); }
+        if (!walkable) { flag_ray(); store(false, 0u, true); }
         else if (s && r.max_t > ftmin) { active = true; cur = a.rootRef; }          /* the root's test is the reference's own: it comes first in every order */
-        else store(false, 0u);
+        else store(false, 0u, false);
     };
 
     for (;;) {
@@ -1516,8 +1529,9 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
                     if (ran) orig = hitLeaf;
                 }
             }
-            if (!(MODE == MODE_MIXED && shadowLane) && hit && (tie || unsettled || !(otherT > hitGate) || !(hitGate < limit0))) flag_ray();
-            store(hit, orig);
+            const bool listed = !(MODE == MODE_MIXED && shadowLane) && hit && (tie || unsettled || !(otherT > hitGate) || !(hitGate < limit0));
+            if (listed) flag_ray();
+            store(hit, orig, listed);
             active = false;
         }
         }   /* if (active) */

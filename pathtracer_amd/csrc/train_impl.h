@@ -172,6 +172,10 @@ static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
             dim3 grid((ctx->W + 31) / 32, (p.row1 - p.row0 + 7) / 8), block(256);
             hipLaunchKernelGGL(k_launch_t<true>, grid, block, 0, p.stream, f);
         }
+        /* certified walk: a short list of jobs for the second walk is walked by the shade launch itself (k_shade_train), unless the
+           host asked for one listed ray per lane throughout */
+        const bool walkInShade = certified && ctx->optSecondWalk != 0 && shaded;
+        TraceArgs second; memset(&second, 0, sizeof(second));
         {   /* every frame in flight one bounce further, and the shadow rays of the bounce before */
             TraceArgs a; fill_trace_args(ctx, a);
             a.stack = t.dRing; a.hitRecs = p.dHitRecs;
@@ -190,7 +194,7 @@ static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
                 HIPCHK(hipEventRecord(timed->first, p.stream));
             }
             if (certified) {
-                if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG)) return rc;
+                if (int rc = launch_cert_mixed(ctx, a, p.stream, k, p.dFlag, p.dCtr + TC_FLAG, walkInShade, &second)) return rc;
             } else if (int rc = launch_mixed(ctx, a, p.stream, k, true)) return rc;
             if (timed) HIPCHK(hipEventRecord(timed->second, p.stream));
         }
@@ -210,7 +214,11 @@ static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
             /* a workgroup for every entry the list can have; those beyond its end (known on the device only) leave at once */
             const uint64_t most = (uint64_t)shaded * ppx;
             const uint64_t blocks = (most + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
-            hipLaunchKernelGGL(k_shade_train, dim3((uint32_t)blocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f);
+            /* in front of them, under the certified walk, the workgroups that walk the listed jobs: one per four jobs of the
+               longest list that is walked this way (those beyond the list's end leave at once) */
+            const uint32_t walkBlocks = walkInShade ? (uint32_t)(PT_SECOND_WALK_SPLIT / (PT_SHADE_BLOCK / 64)) : 0u;
+            if (walkBlocks) hipLaunchKernelGGL(k_shade_train<true>, dim3((uint32_t)blocks + walkBlocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f, second, walkBlocks);
+            else hipLaunchKernelGGL(k_shade_train<false>, dim3((uint32_t)blocks), dim3(PT_SHADE_BLOCK), 0, p.stream, f, second, 0u);
         }
         f.shadowQueue = (uint32_t)q;
         hipLaunchKernelGGL(k_train_step_end, dim3(1), dim3(1), 0, p.stream, f);
