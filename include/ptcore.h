@@ -283,7 +283,8 @@ enum {
                                     reference array fetched and box-tested at a time; 2 (default) = both launches are queued
                                     and the length of the list, which only the device knows, decides which of them works
                                     (a short list is all latency and goes one ray to a wavefront, a long one is throughput
-                                    and goes one to a lane).  Same hits, bit for bit */
+                                    and goes one to a lane); in the frame train the short list is then walked inside the
+                                    shade launch, beside the shading of the jobs that are not on it.  Same hits, bit for bit */
     PT_OPT_SHADOW_STREAM  = 12,  /* inside pt_render_sample[s], where a bounce's shadow pass is a launch of its own: 1 = on a
                                     second stream beside the closest-hit pass of the next bounce; 0 = on the frame's own
                                     stream, after the shade pass (half as many streams: for hosts short of hardware

@@ -172,9 +172,10 @@ static int train_step(PtContext* ctx, bool enter, uint32_t frame_index)
             dim3 grid((ctx->W + 31) / 32, (p.row1 - p.row0 + 7) / 8), block(256);
             hipLaunchKernelGGL(k_launch_t<true>, grid, block, 0, p.stream, f);
         }
-        /* certified walk: a short list of jobs for the second walk is walked by the shade launch itself (k_shade_train), unless the
-           host asked for one listed ray per lane throughout */
-        const bool walkInShade = certified && ctx->optSecondWalk != 0 && shaded;
+        /* certified walk: a short list of jobs for the second walk is walked by the shade launch itself (k_shade_train), which has a
+           workgroup per four jobs of the longest list the device sends that way; where the host has fixed the kind of second walk
+           (PT_OPT_SECOND_WALK 0 or 1) a list of any length is walked by a launch of its own */
+        const bool walkInShade = certified && ctx->optSecondWalk == 2 && shaded;
         TraceArgs second; memset(&second, 0, sizeof(second));
         {   /* every frame in flight one bounce further, and the shadow rays of the bounce before */
             TraceArgs a; fill_trace_args(ctx, a);

@@ -946,6 +946,44 @@ def test_frame_train_random_configurations(bunny, monkey):
             assert np.array_equal(a[3][live].view(np.uint8), b[3][live].view(np.uint8)), f"{desc}: ray stack differs in a live slot ({how})"
 
 
+@pytest.mark.parametrize("doubled", [False, True])
+def test_train_second_walk_settings_short_and_long_lists(gpu_ctx, monkey, doubled):
+    """The frame train under the certified walk with PT_OPT_SECOND_WALK 0, 1 and 2 (the default, under which a short list is
+    walked inside the shade launch and a long one by a launch of its own): every buffer equals what the reference-order walk
+    leaves frame by frame.  CBmonkey lists a handful of jobs per step; with every triangle in the scene twice every hit is a
+    tie, nearly every job is listed, and the lists are far beyond the length at which the device changes the kind of walk."""
+    model = monkey
+    if doubled:
+        idx = np.concatenate([monkey["indices_in"], monkey["indices_in"]])
+        nodes, ridx, _ = pt.build_bvh(monkey["positions"], idx)
+        model = dict(positions=monkey["positions"], aux=monkey["aux"], indices=ridx, nodes=nodes)
+    W, H, NR, NF = 256, 160, 4, 7
+    lights, bn = pt.default_lights(), pt.load_blue_noise()
+    helpers.upload(gpu_ctx, model, lights, bn)
+    gpu_ctx.resize(W, H, NR)
+    c = _consts(model, W, H, NR, 1, {})
+
+    def render(trav, train, second):
+        for o, v in ((core.OPT_TRAVERSAL, trav), (core.OPT_FRAME_TRAIN, train), (core.OPT_SECOND_WALK, second), (core.OPT_TRAIN_PARTS, 2),
+                     (core.OPT_TRAIN_KEEP, 0), (core.OPT_RESEED, 0), (core.OPT_STALE_SLOTS, 0)):
+            gpu_ctx.set_option(o, v)
+        gpu_ctx.set_constants(c)
+        gpu_ctx.clear_accumulation()
+        rc = gpu_ctx.render_samples(1, NF, want_ray_counts=True)
+        return gpu_ctx.readback_accumulation(), gpu_ctx.readback_current(), rc
+
+    try:
+        ref = render(core.TRAVERSAL_FLAT, 0, 2)
+        assert (ref[0][..., 3] == NF).all() and (ref[0][..., :3] > 0).mean() > 0.05
+        for second in (0, 1, 2):
+            got = render(core.TRAVERSAL_CERTIFIED, 1, second)
+            for a, b, what in zip(got, ref, ("accumulation", "current image", "ray counts")):
+                assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), f"second walk {second}: {what} differs"
+    finally:
+        for o, v in ((core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT), (core.OPT_FRAME_TRAIN, 1), (core.OPT_SECOND_WALK, 2)):
+            gpu_ctx.set_option(o, v)
+
+
 @pytest.mark.parametrize("trav,parts", [(core.TRAVERSAL_FLAT_ORDERED, 2), (core.TRAVERSAL_CERTIFIED, 3)])
 def test_traversal_timing_option_counts_launches_and_changes_nothing(gpu_ctx, monkey, trav, parts):
     """PT_OPT_TIME_TRAVERSAL brackets every traversal launch of the frame train with an event pair: a call of N frames has
