@@ -436,10 +436,10 @@ PT_API int pt_trace_rays(PtContext* ctx, const PtRay* d_rays, uint64_t num_rays,
  * walk's list and the spill area of the traversal stacks all live in one static device array of 52 MiB that every GPU
  * the library runs on holds from the first pt_ctx_create on it until the process ends (part of the library's code object:
  * a process pays for it on every GPU it creates a context on, whether or not it ever calls this).  Limits: at most 2^21
- * (2 097 152) rays per call (-1 beyond that), and a tree whose stack need beyond the 12 entries kept in LDS fits the
+ * (2 097 152) rays per call (-1 beyond that), and a tree whose stack need beyond the 11 entries every walk keeps in LDS fits the
  * array's 32 MiB spill area with at least one workgroup per CU (-1 otherwise; a deep tree runs with fewer workgroups
  * than pt_trace_rays would use).  A walk over 64 B or 48 B records needs one stack entry per level of the tree, a walk
- * over treelet records three per two levels: on a 256-CU part that is a depth of 76, or of 50 with
+ * over treelet records three per two levels: on a 256-CU part that is a depth of 75, or of 50 with
  * PT_OPT_RECORD_LAYOUT = 2.  All calls on one GPU share that GPU's array, from whatever context.  Calls from one
  * process take turns on it: every call makes its stream wait for an event recorded behind the previous call's last
  * launch on that GPU (the event is made at pt_ctx_create), so contexts on different streams may call back to back

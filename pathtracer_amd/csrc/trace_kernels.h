@@ -46,7 +46,12 @@
 #endif
 
 #ifndef PT_STACK_LDS
-#define PT_STACK_LDS 12          /* per-lane stack entries held in LDS; deeper entries spill to global memory */
+#define PT_STACK_LDS 13          /* per-lane stack entries held in LDS; deeper entries spill to global memory.  Every entry that moves
+                                    from the spill area into LDS saves traffic (the certified batch kernel: 9 / 10 / 11 entries ->
+                                    27.3 / 26.7 / 26.1 ms); 13 is what fits beside everything else: 20 KB per workgroup of the
+                                    near-first batch kernel (seven per CU), 26.6 KB of the certified frame kernel (five per CU;
+                                    with 14 the other band's passes find no LDS: 172 -> 147 spp/s).  12 / 13 / 14: near-first batch
+                                    23.70 / 23.58 / 23.50 ms, near-first frames 195.5 / 196.7 / 197.4 spp/s */
 #endif
 #ifndef PT_COMPACT_STRIDE
 #define PT_COMPACT_STRIDE 48     /* distance between 48 B records in memory (64 = padded, an experiment) */
