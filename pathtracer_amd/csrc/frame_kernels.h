@@ -44,7 +44,6 @@ enum {
     TC_BASE = 3,          /* where the launch pass puts the new frame's jobs: behind the survivors */
     TC_NSHADOW = 4,       /* two words: lengths of the two shadow queues (one is traced while the other is filled) */
     TC_FLAG = 6,          /* certified walk: jobs listed for a second walk, that walk's fetch counter */
-    TC_LATE = 8,          /* jobs whose second walk runs beside the next step: count, fetch counter */
     TC_WORDS = 16
 };
 
