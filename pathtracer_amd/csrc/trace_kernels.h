@@ -53,6 +53,10 @@
                                     with 14 the other band's passes find no LDS: 172 -> 147 spp/s).  12 / 13 / 14: near-first batch
                                     23.70 / 23.58 / 23.50 ms, near-first frames 195.5 / 196.7 / 197.4 spp/s */
 #endif
+/* where entry e (counted from the first one beyond the LDS part) of this lane's stack sits in the spill area: entry by entry,
+   the lanes of the launch side by side (a lane's entries side by side instead - one line per lane - measured no better on the
+   near-first batch, 23.56 against 23.52 ms, and costs two registers) */
+#define PT_SPILL_AT(e) ((size_t)(e) * totalLanes + gid)
 #ifndef PT_COMPACT_STRIDE
 #define PT_COMPACT_STRIDE 48     /* distance between 48 B records in memory (64 = padded, an experiment) */
 #endif
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
                 /* the sibling waits with its tmin; `max_t > tmin` is re-evaluated when it is popped */
                 const uint16_t tb = hbits((h16)tminSecond);                 /* exact: tmin came from an fp16 */
                 if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = second; sTmin[wave][sp][lane] = tb; }
-                else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(second, tb);
+                else a.overflow[PT_SPILL_AT(sp - PT_STACK_LDS)] = make_uint2(second, tb);
                 sp++;
                 cur = first; needPop = false;
             } else if (pL) { cur = refL; needPop = false; }
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_flat(TraceArgs a)
             const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
             uint32_t ref = sRef[wave][e][lane]; uint16_t tb = sTmin[wave][e][lane];
             asm volatile("" : "+v"(ref));       /* keeps the two sources apart: see above */
-            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; tb = (uint16_t)o.y; }
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[PT_SPILL_AT(sp - PT_STACK_LDS)]; ref = o.x; tb = (uint16_t)o.y; }
             if (r.max_t > (float)hfrombits(tb)) { cur = ref; needPop = false; }
         }
 
@@ -850,7 +854,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
     auto push = [&](uint32_t ref, float tmin) {
         const uint16_t tb = hbits((h16)tmin);                 /* exact: tmin came from an fp16 */
         if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = ref; sTmin[wave][sp][lane] = tb; }
-        else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(ref, tb);
+        else a.overflow[PT_SPILL_AT(sp - PT_STACK_LDS)] = make_uint2(ref, tb);
         sp++;
     };
 
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree(TraceArgs a)
             const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
             uint32_t ref = sRef[wave][e][lane]; uint16_t tb = sTmin[wave][e][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; tb = (uint16_t)o.y; }
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[PT_SPILL_AT(sp - PT_STACK_LDS)]; ref = o.x; tb = (uint16_t)o.y; }
             if (r.max_t > (float)hfrombits(tb)) { cur = ref; needPop = false; }
         }
 
@@ -1058,7 +1062,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree6(TraceArgs a)
     };
     auto push = [&](uint32_t ref, uint32_t gates) {
         if (sp < PT_STACK_LDS) { sRef[wave][sp][lane] = ref; sGate[wave][sp][lane] = gates; }
-        else a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid] = make_uint2(ref, gates);
+        else a.overflow[PT_SPILL_AT(sp - PT_STACK_LDS)] = make_uint2(ref, gates);
         sp++;
     };
 
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(PT_BLOCK) void k_trace_tree6(TraceArgs a)
             const int e = sp < PT_STACK_LDS ? sp : PT_STACK_LDS - 1;
             uint32_t ref = sRef[wave][e][lane], gates = sGate[wave][e][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[(size_t)(sp - PT_STACK_LDS) * totalLanes + gid]; ref = o.x; gates = o.y; }
+            if (sp >= PT_STACK_LDS) { uint2 o = a.overflow[PT_SPILL_AT(sp - PT_STACK_LDS)]; ref = o.x; gates = o.y; }
             const bool parentOk = r.max_t > (float)hi16(gates);
             if (parentOk && r.max_t > (float)lo16(gates)) { cur = ref & ~PT_PAIR_BIT; needPop = false; }
             else if (!parentOk && (ref & PT_PAIR_BIT)) sp--;                /* its sibling beneath hangs on the same parent */
@@ -1485,7 +1489,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
                 const uint16_t gb = hbits((h16)fmaxf(pathGate, tminSecond));             /* exact: both came from fp16 values */
                 const uint32_t bg = (uint32_t)bb | ((uint32_t)gb << 16);
                 if (sp < STK) { sStk[wave][sp][0][lane] = second; sStk[wave][sp][1][lane] = bg; }
-                else a.overflow[(size_t)(sp - STK) * totalLanes + gid] = make_uint2(second, bg);
+                else a.overflow[PT_SPILL_AT(sp - STK)] = make_uint2(second, bg);
                 sp++;
             }
             if (pL || pR) {
@@ -1502,7 +1506,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_CERT_ATTR void k_trace_cert(TraceArgs 
             const int e = sp < STK ? sp : STK - 1;
             uint32_t ref = sStk[wave][e][0][lane], bg = sStk[wave][e][1][lane];
             asm volatile("" : "+v"(ref));
-            if (sp >= STK) { uint2 o = a.overflow[(size_t)(sp - STK) * totalLanes + gid]; ref = o.x; bg = o.y; }
+            if (sp >= STK) { uint2 o = a.overflow[PT_SPILL_AT(sp - STK)]; ref = o.x; bg = o.y; }
             const uint16_t bb = (uint16_t)bg, gb = (uint16_t)(bg >> 16);
             const float waiting = (float)hfrombits(bb);
             const bool enter = (MODE == MODE_MIXED && shadowLane) ? r.max_t > waiting : !(waiting > fmaxf(r.max_t, hitGate));
