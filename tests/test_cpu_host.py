@@ -223,6 +223,39 @@ def test_flatten_pass(bunny):
         pt.flatten_bvh(nodes[:-1], pos, ridx)
 
 
+def test_flatten_pass_half_extent_bound(bunny):
+    """PtNode2.wmax, the per-box constant of the certified walk's entry bound: an fp16 value not below the largest magnitude
+    among the box's six digested half extents plus 2^-12, and the next fp16 value down is below it (rounded up, no further);
+    +inf for a child whose subtree holds a needle triangle (none in CBbunny; a sliver added to a small soup shows it)."""
+    n2, _, _, _ = pt.flatten_bvh(bunny["nodes"], bunny["positions"], bunny["indices"])
+    h = (n2["h"] & 0x7FFF).view(np.float16).astype(np.float64)           # (records, 6, 2)
+    need = h.max(axis=1) + 2.0 ** -12
+    w = n2["wmax"].view(np.float16).astype(np.float64)
+    assert np.isfinite(w).all() and (w >= need).all()
+    below = (n2["wmax"] - 1).view(np.float16).astype(np.float64)
+    assert (below < need).all()
+    # a needle: two edges at an angle of 1e-6 make every box above it one that is never skipped on distance
+    pos = np.ones((9, 4), np.float32)
+    pos[:6, :3] = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [2, 0, 0], [3, 0, 0], [2, 1, 0]], np.float32)
+    pos[6:, :3] = np.array([[5, 0, 0], [6, 0, 0], [7, 1e-6, 0]], np.float32)
+    idx = np.arange(9, dtype=np.uint32).reshape(3, 3)
+    nodes, ridx, _ = pt.build_bvh(pos, idx, 1)
+    m2, tr, _, _ = pt.flatten_bvh(nodes, pos, ridx)
+    thin_leaf = int(np.nonzero(tr["i1"] == 6)[0][0]) | 0x80000000
+    marked = m2["wmax"] == 0x7C00
+    assert marked.any()
+    # the marks are exactly the children whose subtree contains the needle's leaf: its own reference and every ancestor's
+    holds = {}
+    def subtree_has(ref):
+        if ref & 0x80000000:
+            return ref == thin_leaf
+        if ref not in holds:
+            holds[ref] = subtree_has(int(m2["left"][ref])) or subtree_has(int(m2["right"][ref]))
+        return holds[ref]
+    for r in range(m2.shape[0]):
+        assert bool(marked[r, 0]) == subtree_has(int(m2["left"][r])) and bool(marked[r, 1]) == subtree_has(int(m2["right"][r]))
+
+
 def test_flatten_pass_refuses_a_malformed_tree(bunny):
     """A node array that is not the builder's pre-order tree would send a walk round in circles on the device (or the
     flattening pass itself): a right child that points back up, a skip link into the middle of a subtree, a leaf
