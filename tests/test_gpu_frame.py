@@ -946,6 +946,56 @@ def test_frame_train_random_configurations(bunny, monkey):
             assert np.array_equal(a[3][live].view(np.uint8), b[3][live].view(np.uint8)), f"{desc}: ray stack differs in a live slot ({how})"
 
 
+@pytest.mark.parametrize("ntri", [40, 100])
+def test_certified_frames_on_a_comb_tree(gpu_ctx, oracle_lib, ntri):
+    """Whether the reference's walk ran off the end of its array is settled inside the certified pass from the boxes of the
+    path to the array's last node.  A comb - every interior node has a leaf on the left and the rest of the tree on the
+    right - makes that path as long as the tree has triangles and puts a large share of the rays on it: with 40 triangles
+    the table of the path's boxes is used, with 100 the path is longer than the table and such rays take the second walk
+    as they used to.  Either way every buffer is the oracle's, byte for byte."""
+    rng = np.random.default_rng(ntri)
+    pos = np.ones((3 * ntri, 4), np.float32)
+    centre = rng.uniform(-1, 1, (ntri, 1, 3)); centre[:, :, 1] += 1.0
+    pos[:, :3] = (centre + rng.uniform(-0.4, 0.4, (ntri, 3, 3))).reshape(-1, 3).astype(np.float32)
+    pos[-3:, :3] = np.array([[-2.5, 0.0, -2.5], [2.5, 0.0, -2.5], [0.0, 0.3, 3.0]], np.float32)      # the last leaf: a floor under everything
+    idx = np.arange(3 * ntri, dtype=np.uint32).reshape(ntri, 3)
+    aux = np.zeros(3 * ntri, dtype=pt.AUX_DT)
+    aux["normal"] = rng.normal(0, 1, (3 * ntri, 3)).astype(np.float32)
+    aux["color"] = rng.integers(64, 256, (3 * ntri, 4), dtype=np.uint8)
+    aux["color"][:, 3] = 255
+    # pre-order comb: interior node at 2k (left child = leaf 2k+1 holding triangle k, right child = node 2k+2), last node a leaf
+    N = 2 * ntri - 1
+    nodes = np.zeros(N, dtype=pt.NODE_DT)
+    pad = np.float32(6e-5)
+    tri_lo = pos[:, :3].reshape(ntri, 3, 3).min(axis=1) - pad
+    tri_hi = pos[:, :3].reshape(ntri, 3, 3).max(axis=1) + pad
+    suffix_lo = np.minimum.accumulate(tri_lo[::-1], axis=0)[::-1]
+    suffix_hi = np.maximum.accumulate(tri_hi[::-1], axis=0)[::-1]
+    for k in range(ntri - 1):
+        nodes[2 * k] = (suffix_lo[k], 0, suffix_hi[k], 2 * k + 2)                     # skip link 0: its subtree ends the array
+        nodes[2 * k + 1] = (tri_lo[k], 2 * k + 2, tri_hi[k], -3 * k)
+    nodes[N - 1] = (tri_lo[ntri - 1], 0, tri_hi[ntri - 1], -3 * (ntri - 1))
+    model = dict(positions=pos, aux=aux, indices=idx, nodes=nodes)
+    W, H, NR = 96, 64, 4
+    osc, fr = _setup(gpu_ctx, model, W, H, NR)
+    cam = dict(focus_center=(0.0, 1.0, 0.0), orbit_height=1.2, orbit_radius=3.5, orbit_angle=0.4)
+    try:
+        for train in (0, 1):
+            gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_CERTIFIED)
+            gpu_ctx.set_option(core.OPT_FRAME_TRAIN, train)
+            gpu_ctx.clear_accumulation(); fr.clear_accumulation()
+            for frame in (1, 2, 3):
+                c = _consts(model, W, H, NR, frame, cam)
+                gpu_ctx.set_constants(c)
+                gpu_ctx.render_sample(frame)
+                oracle.render_frame(osc, fr, c, mode=oracle.MODE_ZERO_NEXT_SLOT | oracle.MODE_KILL_ON_MISS)
+                _compare(gpu_ctx, fr, live_slots_only=bool(train))
+        assert (gpu_ctx.readback_accumulation()[..., :3] > 0).mean() > 0.2
+    finally:
+        gpu_ctx.set_option(core.OPT_TRAVERSAL, core.TRAVERSAL_DEFAULT)
+        gpu_ctx.set_option(core.OPT_FRAME_TRAIN, 1)
+
+
 @pytest.mark.parametrize("doubled", [False, True])
 def test_train_second_walk_settings_short_and_long_lists(gpu_ctx, monkey, doubled):
     """The frame train under the certified walk with PT_OPT_SECOND_WALK 0, 1 and 2 (the default, under which a short list is
